@@ -1,0 +1,43 @@
+# Builds the product library (librt_mi355x.so, gfx950), the CPU oracle (test infrastructure)
+# and the command-line host.  `make -j8`.
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+ARCH     ?= gfx950
+HOSTDIR  := raytracer_amd/csrc/host
+LIBDIR   := raytracer_amd/lib
+OBJDIR   := build/obj
+
+CXXFLAGS  := -O2 -fPIC -std=c++17 -Wall -Wextra -ffp-contract=off
+HIPFLAGS  := -O3 -fPIC -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -Wall -Wno-unused-parameter
+
+HOST_SRCS := $(HOSTDIR)/json5.cpp $(HOSTDIR)/scene_config.cpp $(HOSTDIR)/obj_loader.cpp \
+             $(HOSTDIR)/image_io.cpp $(HOSTDIR)/flatten.cpp
+HOST_OBJS := $(patsubst $(HOSTDIR)/%.cpp,$(OBJDIR)/%.o,$(HOST_SRCS))
+HOST_HDRS := $(wildcard $(HOSTDIR)/*.hpp) include/rt_mi355x.h
+
+all: $(LIBDIR)/librt_mi355x.so oracle
+
+$(OBJDIR)/%.o: $(HOSTDIR)/%.cpp $(HOST_HDRS)
+	@mkdir -p $(OBJDIR)
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+
+$(OBJDIR)/kernels.o: raytracer_amd/csrc/device/kernels.hip raytracer_amd/csrc/device/rt_device.h include/rt_mi355x.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJDIR)/capi.o: raytracer_amd/csrc/capi.cpp raytracer_amd/csrc/device/rt_device.h $(HOST_HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/librt_mi355x.so: $(HOST_OBJS) $(OBJDIR)/kernels.o $(OBJDIR)/capi.o
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIBDIR)/*.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

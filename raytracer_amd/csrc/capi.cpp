@@ -1,0 +1,770 @@
+// C ABI of librt_mi355x.so (include/rt_mi355x.h): scene files -> flattened arrays on the
+// host, and the per-GPU render context that owns the HBM-resident scene, the ray queues
+// and the HIP stream the wavefront kernels run on.
+//
+// There is deliberately no CPU fallback here: every compute entry point needs a HIP device
+// and fails with RT_ERR_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "device/rt_device.h"
+#include "host/flatten.hpp"
+#include "host/json5.hpp"
+#include "host/scene_config.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+struct RtError {
+    int code;
+    std::string msg;
+};
+
+#define HIP_CHECK(expr)                                                                               \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            throw RtError{RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)};          \
+    } while (0)
+
+template <typename T>
+struct DevBuf {  // owning device allocation
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void ensure(size_t count) {
+        if (count <= n) return;
+        release();
+        HIP_CHECK(hipMalloc((void**)&p, (count ? count : 1) * sizeof(T)));
+        n = count;
+    }
+    void upload(const std::vector<T>& v) {
+        ensure(v.size() ? v.size() : 1);
+        if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+};
+
+// ---- scene description validation: every index a kernel will follow is checked here, on
+// the host, so that a malformed description is an error code and never a GPU fault.
+void validate(const rt_scene_desc& d) {
+    auto bad = [](const std::string& m) { throw RtError{RT_ERR_INVALID, "scene description: " + m}; };
+    auto need = [&](const void* p, uint64_t n, const char* what) {
+        if (n && !p) bad(std::string(what) + " is null");
+    };
+    need(d.nodes, d.n_nodes, "nodes");
+    need(d.objects, d.n_objects, "objects");
+    need(d.xforms, d.n_xforms, "xforms");
+    need(d.spheres, d.n_spheres, "spheres");
+    need(d.moving_spheres, d.n_moving_spheres, "moving_spheres");
+    need(d.rects, d.n_rects, "rects");
+    need(d.triangles, d.n_triangles, "triangles");
+    need(d.planes, d.n_planes, "planes");
+    need(d.media, d.n_media, "media");
+    need(d.materials, d.n_materials, "materials");
+    need(d.images, d.n_images, "images");
+    need(d.texels, d.n_texel_bytes, "texels");
+    need(d.top_list, d.n_top, "top_list");
+    if (d.n_top == 0) bad("empty world");
+    if (d.n_nodes > 0x7fffffffull || d.n_objects > 0x7fffffffull || d.n_triangles > 0x7fffffffull ||
+        d.n_materials >= 0x7fffffffull)
+        bad("too many elements");
+    if (d.stack_depth < 0 || d.stack_depth > 64) bad("BVH too deep for the traversal stack (64 entries)");
+    auto mat_ok = [&](int32_t m) { return m >= 0 && (uint64_t)m < d.n_materials; };
+    for (uint64_t i = 0; i < d.n_materials; i++) {
+        const rt_material& m = d.materials[i];
+        if (m.type < RT_MAT_LAMBERTIAN || m.type > RT_MAT_CHECKERED) bad("material type");
+        if (m.image >= 0 && (uint64_t)m.image >= d.n_images) bad("material image index");
+        if (m.type == RT_MAT_CHECKERED) {
+            // Parts must precede nothing in particular, but must not loop: follow the chain.
+            if (!mat_ok(m.odd) || !mat_ok(m.even)) bad("checkered part index");
+        }
+    }
+    {  // checkered nesting must be acyclic (the reference builds parts first, src/config.rs:143-159)
+        std::vector<int> state(d.n_materials, 0);
+        std::vector<std::pair<int32_t, int>> stack;
+        for (uint64_t r = 0; r < d.n_materials; r++) {
+            if (state[r]) continue;
+            stack.push_back({(int32_t)r, 0});
+            while (!stack.empty()) {
+                auto& top = stack.back();
+                const rt_material& m = d.materials[top.first];
+                if (top.second == 0) state[top.first] = 1;
+                if (m.type != RT_MAT_CHECKERED || top.second == 2) {
+                    state[top.first] = 2;
+                    stack.pop_back();
+                    continue;
+                }
+                int32_t child = top.second == 0 ? m.odd : m.even;
+                top.second++;
+                if (state[child] == 1) bad("checkered materials form a cycle");
+                if (state[child] == 0) stack.push_back({child, 0});
+            }
+        }
+    }
+    for (uint64_t i = 0; i < d.n_images; i++) {
+        const rt_image& im = d.images[i];
+        if (im.width <= 0 || im.height <= 0) bad("image size");
+        if (im.texel_offset + (uint64_t)im.width * im.height * 3 > d.n_texel_bytes) bad("image texel range");
+    }
+    for (uint64_t i = 0; i < d.n_spheres; i++)
+        if (!mat_ok(d.spheres[i].material)) bad("sphere material");
+    for (uint64_t i = 0; i < d.n_moving_spheres; i++)
+        if (!mat_ok(d.moving_spheres[i].material)) bad("moving sphere material");
+    for (uint64_t i = 0; i < d.n_rects; i++) {
+        if (!mat_ok(d.rects[i].material)) bad("rect material");
+        if (d.rects[i].axis < 0 || d.rects[i].axis > 2) bad("rect axis");
+    }
+    for (uint64_t i = 0; i < d.n_triangles; i++)
+        if (!mat_ok(d.triangles[i].material)) bad("triangle material");
+    for (uint64_t i = 0; i < d.n_planes; i++)
+        if (!mat_ok(d.planes[i].material)) bad("plane material");
+    // BVH: children in range, every subtree reached once (no cycles), leaf payloads in range.
+    std::vector<char> seen(d.n_nodes, 0);
+    auto walk = [&](int32_t root, int leaf_kind) {
+        if (root < 0 || (uint64_t)root >= d.n_nodes) bad("BVH root index");
+        if (seen[root] == 2) return;  // a BLAS shared by several instances: checked already
+        std::vector<int32_t> st{root};
+        while (!st.empty()) {
+            int32_t n = st.back();
+            st.pop_back();
+            if (seen[n]) bad("BVH node reached twice");
+            seen[n] = 1;
+            const rt_node& nd = d.nodes[n];
+            if (nd.left < 0) {
+                int64_t payload = -1 - (int64_t)nd.left;
+                if (nd.right != leaf_kind) bad("BVH leaf kind");
+                if (leaf_kind == RT_LEAF_OBJECT ? (uint64_t)payload >= d.n_objects : (uint64_t)payload >= d.n_triangles)
+                    bad("BVH leaf payload");
+            } else {
+                if ((uint64_t)nd.left >= d.n_nodes || nd.right < 0 || (uint64_t)nd.right >= d.n_nodes)
+                    bad("BVH child index");
+                st.push_back(nd.left);
+                st.push_back(nd.right);
+            }
+        }
+        seen[root] = 2;
+    };
+    for (uint64_t i = 0; i < d.n_media; i++) {
+        const rt_medium& m = d.media[i];
+        if (!mat_ok(m.material)) bad("medium material");
+        if (m.boundary_object < 0 || (uint64_t)m.boundary_object >= d.n_objects) bad("medium boundary index");
+        if (d.objects[m.boundary_object].kind == RT_OBJ_MEDIUM) bad("medium boundary is a medium");
+    }
+    for (uint64_t i = 0; i < d.n_objects; i++) {
+        const rt_object& o = d.objects[i];
+        if (o.xform < -1 || (o.xform >= 0 && (uint64_t)o.xform >= d.n_xforms)) bad("object xform index");
+        uint64_t limit = 0;
+        switch (o.kind) {
+            case RT_OBJ_SPHERE: limit = d.n_spheres; break;
+            case RT_OBJ_MOVING_SPHERE: limit = d.n_moving_spheres; break;
+            case RT_OBJ_RECTS: limit = d.n_rects; break;
+            case RT_OBJ_TRIANGLE: limit = d.n_triangles; break;
+            case RT_OBJ_PLANE: limit = d.n_planes; break;
+            case RT_OBJ_MEDIUM: limit = d.n_media; break;
+            case RT_OBJ_BLAS: walk(o.first, RT_LEAF_TRIANGLE); continue;
+            default: bad("object kind");
+        }
+        int64_t count = o.kind == RT_OBJ_RECTS ? o.count : 1;
+        if (o.first < 0 || count < 1 || (uint64_t)o.first + (uint64_t)count > limit) bad("object primitive range");
+    }
+    bool uses_bvh = false;
+    for (uint64_t i = 0; i < d.n_top; i++) {
+        int32_t e = d.top_list[i];
+        if (e == RT_TOP_BVH) uses_bvh = true;
+        else if (e < 0 || (uint64_t)e >= d.n_objects) bad("top_list entry");
+    }
+    if (uses_bvh) walk(d.tlas_root, RT_LEAF_OBJECT);
+}
+
+template <typename T> void cvt3(T* o, const double* s) { o[0] = (T)s[0]; o[1] = (T)s[1]; o[2] = (T)s[2]; }
+
+struct EngineBase {
+    virtual ~EngineBase() {}
+    virtual void upload(const rt_scene_desc& d) = 0;
+    virtual void trace(const rt_ray* rays, size_t n, uint64_t seed, rt_hit* out) = 0;
+    virtual void primary_rays(uint32_t W, uint32_t H, uint32_t j0, uint32_t j1, uint32_t sample, uint64_t seed, rt_ray* out) = 0;
+    virtual void render_accum(uint32_t W, uint32_t H, uint32_t j0, uint32_t j1, uint32_t s0, uint32_t ns,
+                              uint32_t max_bounces, uint64_t seed, double* accum_dev, rt_stats* stats) = 0;
+};
+
+template <typename T>
+struct Engine : EngineBase {
+    hipStream_t stream;
+    int num_cus;
+    uint64_t max_paths;
+    bool have_scene = false;
+    int stack_depth = 16;
+    rtd::DScene<T> S;
+    DevBuf<rtd::DNode<T>> nodes;
+    DevBuf<rtd::DObject> objects;
+    DevBuf<rtd::DXform<T>> xforms;
+    DevBuf<rtd::DSphere<T>> spheres;
+    DevBuf<rtd::DMovingSphere<T>> moving_spheres;
+    DevBuf<rtd::DRect<T>> rects;
+    DevBuf<rtd::DTriangle<T>> triangles;
+    DevBuf<rtd::DPlane<T>> planes;
+    DevBuf<rtd::DMedium<T>> media;
+    DevBuf<rtd::DMaterial<T>> materials;
+    DevBuf<rtd::DImage> images;
+    DevBuf<uint8_t> texels;
+    DevBuf<int32_t> top_list;
+    // work buffers
+    DevBuf<T> qslab[2], hslab, sample_rgb, tminmax;
+    DevBuf<uint32_t> qpid[2], hmat;
+    DevBuf<int32_t> hids;
+    DevBuf<uint32_t> counts;
+    DevBuf<unsigned long long> ray_total;
+    DevBuf<double> io_f64;
+    DevBuf<rt_hit> io_hits;
+    size_t capacity = 0;
+    uint32_t* host_counts = nullptr;  // pinned
+    std::vector<hipEvent_t> events;
+
+    Engine(hipStream_t st, int cus, uint64_t maxp) : stream(st), num_cus(cus), max_paths(maxp) {
+        std::memset(&S, 0, sizeof(S));
+        HIP_CHECK(hipHostMalloc((void**)&host_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
+        counts.ensure(2);
+        ray_total.ensure(1);
+    }
+    ~Engine() override {
+        if (host_counts) (void)hipHostFree(host_counts);
+        for (auto e : events) (void)hipEventDestroy(e);
+    }
+
+    void upload(const rt_scene_desc& d) override {
+        validate(d);
+        have_scene = false;
+        {
+            std::vector<rtd::DNode<T>> v(d.n_nodes);
+            for (size_t i = 0; i < v.size(); i++) {
+                cvt3(v[i].lo, d.nodes[i].lo);
+                cvt3(v[i].hi, d.nodes[i].hi);
+                if (sizeof(T) == 4 && d.nodes[i].left >= 0) {
+                    // f32 boxes are rounded outwards so that narrowing can never cull a hit the f64
+                    // box admits.  (Side effect, fast mode only: a zero-thickness box no longer
+                    // culls itself as it does in the reference)
+                    for (int k = 0; k < 3; k++) {
+                        if ((double)v[i].lo[k] > d.nodes[i].lo[k]) v[i].lo[k] = (T)std::nextafterf((float)v[i].lo[k], -INFINITY);
+                        if ((double)v[i].hi[k] < d.nodes[i].hi[k]) v[i].hi[k] = (T)std::nextafterf((float)v[i].hi[k], INFINITY);
+                    }
+                }
+                v[i].left = d.nodes[i].left;
+                v[i].right = d.nodes[i].right;
+            }
+            nodes.upload(v);
+        }
+        {
+            std::vector<rtd::DObject> v(d.n_objects);
+            for (size_t i = 0; i < v.size(); i++) {
+                const rt_object& o = d.objects[i];
+                v[i] = rtd::DObject{o.kind, o.xform, o.first, o.count, o.world_index, {0, 0, 0}};
+            }
+            objects.upload(v);
+        }
+        {
+            std::vector<rtd::DXform<T>> v(d.n_xforms);
+            for (size_t i = 0; i < v.size(); i++) {
+                for (int k = 0; k < 9; k++) v[i].m[k] = (T)d.xforms[i].m[k];
+                cvt3(v[i].b, d.xforms[i].b);
+            }
+            xforms.upload(v);
+        }
+        {
+            std::vector<rtd::DSphere<T>> v(d.n_spheres);
+            for (size_t i = 0; i < v.size(); i++) {
+                cvt3(v[i].centre, d.spheres[i].centre);
+                v[i].radius = (T)d.spheres[i].radius;
+                v[i].material = d.spheres[i].material;
+                v[i].owner = d.spheres[i].owner;
+            }
+            spheres.upload(v);
+        }
+        {
+            std::vector<rtd::DMovingSphere<T>> v(d.n_moving_spheres);
+            for (size_t i = 0; i < v.size(); i++) {
+                const rt_moving_sphere& s = d.moving_spheres[i];
+                cvt3(v[i].centre0, s.centre0);
+                cvt3(v[i].centre1, s.centre1);
+                v[i].time0 = (T)s.time0; v[i].time1 = (T)s.time1; v[i].radius = (T)s.radius;
+                v[i].material = s.material;
+                v[i].owner = s.owner;
+            }
+            moving_spheres.upload(v);
+        }
+        {
+            std::vector<rtd::DRect<T>> v(d.n_rects);
+            for (size_t i = 0; i < v.size(); i++) {
+                const rt_rect& r = d.rects[i];
+                v[i].a0 = (T)r.a0; v[i].a1 = (T)r.a1; v[i].b0 = (T)r.b0; v[i].b1 = (T)r.b1; v[i].k = (T)r.k;
+                v[i].axis = r.axis; v[i].facing_positive = r.facing_positive;
+                v[i].material = r.material; v[i].owner = r.owner; v[i].sub = r.sub; v[i].pad = 0;
+            }
+            rects.upload(v);
+        }
+        {
+            std::vector<rtd::DTriangle<T>> v(d.n_triangles);
+            for (size_t i = 0; i < v.size(); i++) {
+                const rt_triangle& t = d.triangles[i];
+                cvt3(v[i].point, t.point); cvt3(v[i].vec1, t.vec1); cvt3(v[i].vec2, t.vec2); cvt3(v[i].normal, t.normal);
+                v[i].material = t.material; v[i].owner = t.owner; v[i].sub = t.sub; v[i].pad = 0;
+            }
+            triangles.upload(v);
+        }
+        {
+            std::vector<rtd::DPlane<T>> v(d.n_planes);
+            for (size_t i = 0; i < v.size(); i++) {
+                const rt_plane& p = d.planes[i];
+                cvt3(v[i].point, p.point); cvt3(v[i].vec1, p.vec1); cvt3(v[i].vec2, p.vec2); cvt3(v[i].normal, p.normal);
+                v[i].uv_repeat = (T)p.uv_repeat;
+                v[i].material = p.material; v[i].owner = p.owner;
+            }
+            planes.upload(v);
+        }
+        {
+            std::vector<rtd::DMedium<T>> v(d.n_media);
+            for (size_t i = 0; i < v.size(); i++) {
+                const rt_medium& m = d.media[i];
+                v[i].neg_inv_density = (T)m.neg_inv_density;
+                v[i].boundary_object = m.boundary_object; v[i].material = m.material; v[i].owner = m.owner;
+                v[i].rng_key = m.rng_key & 0x7fffffffu;
+            }
+            media.upload(v);
+        }
+        {
+            std::vector<rtd::DMaterial<T>> v(d.n_materials);
+            for (size_t i = 0; i < v.size(); i++) {
+                const rt_material& m = d.materials[i];
+                cvt3(v[i].colour, m.colour);
+                v[i].param = (T)m.param;
+                v[i].type = m.type; v[i].image = m.image; v[i].odd = m.odd; v[i].even = m.even;
+            }
+            materials.upload(v);
+        }
+        {
+            std::vector<rtd::DImage> v(d.n_images);
+            for (size_t i = 0; i < v.size(); i++) v[i] = rtd::DImage{d.images[i].width, d.images[i].height, d.images[i].texel_offset};
+            images.upload(v);
+        }
+        texels.upload(std::vector<uint8_t>(d.texels, d.texels + d.n_texel_bytes));
+        top_list.upload(std::vector<int32_t>(d.top_list, d.top_list + d.n_top));
+        S.nodes = nodes.p; S.objects = objects.p; S.xforms = xforms.p; S.spheres = spheres.p;
+        S.moving_spheres = moving_spheres.p; S.rects = rects.p; S.triangles = triangles.p; S.planes = planes.p;
+        S.media = media.p; S.materials = materials.p; S.images = images.p; S.texels = texels.p;
+        S.top_list = top_list.p;
+        S.n_top = (int32_t)d.n_top;
+        S.tlas_root = d.tlas_root;
+        const rt_camera& c = d.camera;
+        cvt3(S.camera.origin, c.origin); cvt3(S.camera.lower_left_corner, c.lower_left_corner);
+        cvt3(S.camera.horizontal, c.horizontal); cvt3(S.camera.vertical, c.vertical);
+        cvt3(S.camera.u, c.u); cvt3(S.camera.v, c.v);
+        S.camera.lens_radius = (T)c.lens_radius; S.camera.start_time = (T)c.start_time; S.camera.end_time = (T)c.end_time;
+        S.sky.gradient = d.sky.gradient;
+        cvt3(S.sky.colour, d.sky.colour); cvt3(S.sky.unit_dir, d.sky.unit_dir);
+        cvt3(S.sky.colour0, d.sky.colour0); cvt3(S.sky.colour1, d.sky.colour1);
+        stack_depth = d.stack_depth;
+        have_scene = true;
+    }
+
+    void ensure_capacity(size_t n, bool with_ids) {
+        if (n > capacity) {
+            for (int k = 0; k < 2; k++) {
+                qslab[k].ensure(n * 10);
+                qpid[k].ensure(n);
+            }
+            hslab.ensure(n * 6);
+            hmat.ensure(n);
+            capacity = n;
+        }
+        if (with_ids) {
+            hids.ensure(capacity * 3);
+            tminmax.ensure(capacity * 2);
+        }
+    }
+    rtd::DQueue<T> queue(int k) {
+        T* b = qslab[k].p;
+        size_t n = capacity;
+        return rtd::DQueue<T>{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, qpid[k].p};
+    }
+    rtd::DHits<T> hits(bool with_ids) {
+        T* b = hslab.p;
+        size_t n = capacity;
+        rtd::DHits<T> h{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, hmat.p, nullptr, nullptr, nullptr};
+        if (with_ids) {
+            h.owner = hids.p;
+            h.sub = hids.p + n;
+            h.world_index = hids.p + 2 * n;
+        }
+        return h;
+    }
+    int grid_for(size_t n) {
+        size_t blocks = (n + 255) / 256;
+        size_t cap = (size_t)num_cus * 8;
+        return (int)(blocks < 1 ? 1 : blocks > cap ? cap : blocks);
+    }
+    void need_scene() {
+        if (!have_scene) throw RtError{RT_ERR_NO_SCENE, "no scene uploaded (call rt_upload_scene first)"};
+    }
+
+    void trace(const rt_ray* rays, size_t n, uint64_t seed, rt_hit* out) override {
+        need_scene();
+        static_assert(sizeof(rt_ray) == 9 * sizeof(double), "rt_ray layout");
+        size_t chunk_max = (size_t)std::min<uint64_t>(max_paths, 1u << 24);
+        for (size_t base = 0; base < n; base += chunk_max) {
+            size_t m = std::min(chunk_max, n - base);
+            ensure_capacity(m, true);
+            io_f64.ensure(m * 9);
+            io_hits.ensure(m);
+            HIP_CHECK(hipMemcpyAsync(io_f64.p, rays + base, m * sizeof(rt_ray), hipMemcpyHostToDevice, stream));
+            rtd::DBatch B{0, 0, 0, 1, (uint32_t)base, 1u, seed};
+            rtd::DQueue<T> q = queue(0);
+            rtd::DHits<T> h = hits(true);
+            T* tmin = tminmax.p;
+            T* tmax = tminmax.p + capacity;
+            rtd::Launch<T>::load_rays(io_f64.p, (uint32_t)m, q, tmin, tmax, counts.p, stream);
+            rtd::Launch<T>::extend(S, B, q, h, tmin, tmax, 0, counts.p, nullptr, nullptr, stack_depth, grid_for(m), stream);
+            rtd::Launch<T>::store_hits(q, h, (uint32_t)m, io_hits.p, stream);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(out + base, io_hits.p, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+        }
+    }
+
+    void primary_rays(uint32_t W, uint32_t H, uint32_t j0, uint32_t j1, uint32_t sample, uint64_t seed, rt_ray* out) override {
+        need_scene();
+        size_t n = (size_t)W * (j1 - j0);
+        if (n == 0) return;
+        if (n > max_paths) throw RtError{RT_ERR_INVALID, "rt_primary_rays: band larger than max_paths"};
+        ensure_capacity(n, false);
+        io_f64.ensure(n * 9);
+        rtd::DBatch B{W, H, j0, (uint32_t)n, sample, 0u, seed};
+        rtd::DQueue<T> q = queue(0);
+        rtd::Launch<T>::raygen(S, B, q, (uint32_t)n, counts.p, stream);
+        rtd::Launch<T>::store_rays(q, (uint32_t)n, io_f64.p, stream);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out, io_f64.p, n * sizeof(rt_ray), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    hipEvent_t event(size_t k) {
+        while (events.size() <= k) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreate(&e));
+            events.push_back(e);
+        }
+        return events[k];
+    }
+
+    void render_accum(uint32_t W, uint32_t H, uint32_t j0, uint32_t j1, uint32_t s0, uint32_t ns, uint32_t max_bounces,
+                      uint64_t seed, double* accum_dev, rt_stats* stats) override {
+        need_scene();
+        if (stats) std::memset(stats, 0, sizeof(*stats));
+        uint64_t npix = (uint64_t)W * (j1 - j0);
+        if (npix == 0 || ns == 0) return;
+        if (npix > max_paths || npix > 0xffffffffull)
+            throw RtError{RT_ERR_INVALID, "row band holds more pixels than max_paths; render fewer rows per call"};
+        uint64_t spb_cap = std::max<uint64_t>(1, max_paths / npix);
+        uint32_t n_batches = (uint32_t)((ns + spb_cap - 1) / spb_cap);
+        uint32_t spb = (ns + n_batches - 1) / n_batches;
+        ensure_capacity((size_t)(npix * spb), false);
+        sample_rgb.ensure((size_t)(npix * spb) * 3);
+        HIP_CHECK(hipMemsetAsync(ray_total.p, 0, sizeof(unsigned long long), stream));
+        size_t ev = 0;
+        const bool timing = stats != nullptr;
+        std::vector<std::pair<size_t, int>> spans;  // (first event index, 0 = extend / 1 = shade)
+        hipEvent_t ev_begin = event(ev++), ev_end = event(ev++);
+        if (timing) HIP_CHECK(hipEventRecord(ev_begin, stream));
+        uint32_t deepest = 0;
+        for (uint32_t b = 0; b < n_batches; b++) {
+            uint32_t bs0 = s0 + b * spb;
+            uint32_t bns = std::min(spb, s0 + ns - bs0);
+            uint32_t n_paths = (uint32_t)(npix * bns);
+            rtd::DBatch B{W, H, j0, (uint32_t)npix, bs0, 0u, seed};
+            HIP_CHECK(hipMemsetAsync(sample_rgb.p, 0, (size_t)n_paths * 3 * sizeof(T), stream));
+            rtd::Launch<T>::raygen(S, B, queue(0), n_paths, counts.p, stream);
+            int grid = grid_for(n_paths);
+            for (uint32_t depth = 0; depth < max_bounces; depth++) {
+                int in = depth & 1, out = in ^ 1;
+                if (timing) {
+                    spans.push_back({ev, 0});
+                    HIP_CHECK(hipEventRecord(event(ev), stream));
+                }
+                rtd::Launch<T>::extend(S, B, queue(in), hits(false), nullptr, nullptr, depth, counts.p + in, counts.p + out,
+                                       ray_total.p, stack_depth, grid, stream);
+                if (timing) {
+                    HIP_CHECK(hipEventRecord(event(ev + 1), stream));
+                    spans.push_back({ev + 1, 1});
+                }
+                rtd::Launch<T>::shade(S, B, queue(in), hits(false), queue(out), sample_rgb.p, depth, max_bounces,
+                                      counts.p + in, counts.p + out, grid, stream);
+                if (timing) HIP_CHECK(hipEventRecord(event(ev + 2), stream));
+                ev += 3;
+                deepest = std::max(deepest, depth + 1);
+                if ((depth & 3) == 3 && depth + 1 < max_bounces) {
+                    // Every 4th bounce: is anything still alive?  (One 4-byte read-back.)
+                    HIP_CHECK(hipMemcpyAsync(host_counts, counts.p + out, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    if (host_counts[0] == 0) break;
+                }
+            }
+            rtd::Launch<T>::accumulate(sample_rgb.p, (uint32_t)npix, bns, accum_dev, stream);
+            HIP_CHECK(hipGetLastError());
+        }
+        if (timing) HIP_CHECK(hipEventRecord(ev_end, stream));
+        unsigned long long total = 0;
+        HIP_CHECK(hipMemcpyAsync(&total, ray_total.p, sizeof(total), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (stats) {
+            stats->rays = total;
+            stats->paths = npix * ns;
+            stats->batches = n_batches;
+            stats->max_depth_reached = deepest;
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev_begin, ev_end));
+            stats->ms_total = ms;
+            for (auto& sp : spans) {
+                HIP_CHECK(hipEventElapsedTime(&ms, events[sp.first], events[sp.first + 1]));
+                if (sp.second == 0) {
+                    stats->ms_extend += ms;
+                    stats->extend_launches++;
+                } else {
+                    stats->ms_shade += ms;
+                    stats->shade_launches++;
+                }
+            }
+        }
+    }
+};
+
+}  // namespace
+
+struct rt_scene {
+    rt::Scene scene;
+    rt::FlatScene flat;
+    rt_scene_desc desc;
+};
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::unique_ptr<EngineBase> engine;
+    std::string error;
+    uint64_t max_paths = 0;
+    DevBuf<double> tmp_accum;
+    DevBuf<uint8_t> tmp_rgb8;
+};
+
+template <typename F>
+static int guard_global(F&& f) {
+    try {
+        f();
+        return RT_OK;
+    } catch (const RtError& e) {
+        g_error = e.msg;
+        return e.code;
+    } catch (const rt::SceneError& e) {
+        g_error = e.what();
+        return RT_ERR_SCENE;
+    } catch (const rt::Json5Error& e) {
+        g_error = e.what();
+        return RT_ERR_SCENE;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return RT_ERR_INVALID;
+    }
+}
+
+template <typename F>
+static int guard(rt_context* ctx, F&& f) {
+    if (!ctx) {
+        g_error = "null context";
+        return RT_ERR_INVALID;
+    }
+    int rc = guard_global([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        f();
+    });
+    if (rc != RT_OK) ctx->error = g_error;
+    return rc;
+}
+
+extern "C" {
+
+const char* rt_last_global_error(void) { return g_error.c_str(); }
+
+static int load_scene_impl(rt::Scene&& sc, rt_scene** out) {
+    std::unique_ptr<rt_scene> s(new rt_scene);
+    s->scene = std::move(sc);
+    s->flat = rt::flatten_scene(s->scene);
+    s->desc = s->flat.desc();
+    *out = s.release();
+    return RT_OK;
+}
+
+int rt_scene_load_file(const char* path, const char* asset_root, rt_scene** out) {
+    if (!path || !out) {
+        g_error = "rt_scene_load_file: null argument";
+        return RT_ERR_INVALID;
+    }
+    *out = nullptr;
+    return guard_global([&] { load_scene_impl(rt::load_scene_file(path, asset_root ? asset_root : ""), out); });
+}
+
+int rt_scene_load_text(const char* text, const char* asset_root, rt_scene** out) {
+    if (!text || !out) {
+        g_error = "rt_scene_load_text: null argument";
+        return RT_ERR_INVALID;
+    }
+    *out = nullptr;
+    return guard_global([&] { load_scene_impl(rt::load_scene_text(text, asset_root ? asset_root : ""), out); });
+}
+
+void rt_scene_free(rt_scene* scene) { delete scene; }
+
+const rt_scene_desc* rt_scene_get_desc(const rt_scene* scene) { return scene ? &scene->desc : nullptr; }
+
+uint32_t rt_scene_image_height(const rt_scene* scene, uint32_t width) {
+    return scene ? scene->scene.image_height(width) : 0;
+}
+
+int rt_create(int device_id, const rt_options* options, rt_context** out) {
+    if (!out) {
+        g_error = "rt_create: null out pointer";
+        return RT_ERR_INVALID;
+    }
+    *out = nullptr;
+    return guard_global([&] {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count == 0)
+            throw RtError{RT_ERR_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e)};
+        if (device_id < 0 || device_id >= count) throw RtError{RT_ERR_INVALID, "rt_create: device id out of range"};
+        HIP_CHECK(hipSetDevice(device_id));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+        std::unique_ptr<rt_context> ctx(new rt_context);
+        ctx->device = device_id;
+        HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        int precision = options ? options->precision : RT_PRECISION_F64;
+        uint64_t max_paths = options && options->max_paths ? options->max_paths : (1ull << 25);
+        if (max_paths > 0xffffffffull) max_paths = 0xffffffffull;
+        if (precision == RT_PRECISION_F64)
+            ctx->engine.reset(new Engine<double>(ctx->stream, prop.multiProcessorCount, max_paths));
+        else if (precision == RT_PRECISION_F32)
+            ctx->engine.reset(new Engine<float>(ctx->stream, prop.multiProcessorCount, max_paths));
+        else
+            throw RtError{RT_ERR_INVALID, "rt_create: unknown precision"};
+        ctx->max_paths = max_paths;
+        *out = ctx.release();
+    });
+}
+
+void rt_destroy(rt_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    ctx->engine.reset();
+    ctx->tmp_accum.release();
+    ctx->tmp_rgb8.release();
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+
+int rt_upload_scene(rt_context* ctx, const rt_scene_desc* scene) {
+    return guard(ctx, [&] {
+        if (!scene) throw RtError{RT_ERR_INVALID, "rt_upload_scene: null scene"};
+        ctx->engine->upload(*scene);
+    });
+}
+
+int rt_trace(rt_context* ctx, const rt_ray* rays, size_t n, uint64_t seed, rt_hit* out) {
+    return guard(ctx, [&] {
+        if (n == 0) return;
+        if (!rays || !out) throw RtError{RT_ERR_INVALID, "rt_trace: null buffer"};
+        ctx->engine->trace(rays, n, seed, out);
+    });
+}
+
+int rt_primary_rays(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0, uint32_t j1, uint32_t sample,
+                    uint64_t seed, rt_ray* out) {
+    return guard(ctx, [&] {
+        if (width < 2 || height < 2 || j0 > j1 || j1 > height) throw RtError{RT_ERR_INVALID, "rt_primary_rays: bad image geometry"};
+        if (!out) throw RtError{RT_ERR_INVALID, "rt_primary_rays: null buffer"};
+        ctx->engine->primary_rays(width, height, j0, j1, sample, seed, out);
+    });
+}
+
+int rt_render_accum_device(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0, uint32_t j1, uint32_t s0,
+                           uint32_t n_samples, uint32_t max_bounces, uint64_t seed, double* accum_dev, rt_stats* stats) {
+    return guard(ctx, [&] {
+        if (width < 2 || height < 2 || j0 > j1 || j1 > height)
+            throw RtError{RT_ERR_INVALID, "rt_render_accum_device: bad image geometry (width, height >= 2, j0 <= j1 <= height)"};
+        if (!accum_dev && j1 > j0 && n_samples) throw RtError{RT_ERR_INVALID, "rt_render_accum_device: null accum buffer"};
+        if ((uint64_t)s0 + n_samples > 0xffffffffull) throw RtError{RT_ERR_INVALID, "sample index overflow"};
+        ctx->engine->render_accum(width, height, j0, j1, s0, n_samples, max_bounces, seed, accum_dev, stats);
+    });
+}
+
+int rt_quantize_device(rt_context* ctx, const double* accum_dev, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb8_dev) {
+    return guard(ctx, [&] {
+        if (n_pixels == 0) return;
+        if (!accum_dev || !rgb8_dev) throw RtError{RT_ERR_INVALID, "rt_quantize_device: null buffer"};
+        rtd::launch_quantize(accum_dev, n_pixels, spp_total, rgb8_dev, ctx->stream);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int rt_render_rows(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0, uint32_t j1, uint32_t spp,
+                   uint32_t max_bounces, uint64_t seed, uint8_t* rgb8, double* sum_rgb, rt_stats* stats) {
+    return guard(ctx, [&] {
+        if (width < 2 || height < 2 || j0 > j1 || j1 > height)
+            throw RtError{RT_ERR_INVALID, "rt_render_rows: bad image geometry (width, height >= 2, j0 <= j1 <= height)"};
+        if (stats) std::memset(stats, 0, sizeof(*stats));
+        uint64_t npix = (uint64_t)width * (j1 - j0);
+        if (npix == 0) return;
+        ctx->tmp_accum.ensure(npix * 3);
+        ctx->tmp_rgb8.ensure(npix * 3);
+        HIP_CHECK(hipMemsetAsync(ctx->tmp_accum.p, 0, npix * 3 * sizeof(double), ctx->stream));
+        // Bands of whole rows that fit the path budget (each pixel's samples stay together).
+        uint32_t rows_per_band = (uint32_t)std::max<uint64_t>(1, ctx->max_paths / width);
+        for (uint32_t b0 = j0; b0 < j1; b0 += rows_per_band) {
+            uint32_t b1 = std::min(j1, b0 + rows_per_band);
+            rt_stats part;
+            ctx->engine->render_accum(width, height, b0, b1, 0, spp, max_bounces, seed,
+                                      ctx->tmp_accum.p + (uint64_t)(b0 - j0) * width * 3, stats ? &part : nullptr);
+            if (stats) {
+                stats->rays += part.rays; stats->paths += part.paths;
+                stats->ms_total += part.ms_total; stats->ms_extend += part.ms_extend; stats->ms_shade += part.ms_shade;
+                stats->extend_launches += part.extend_launches; stats->shade_launches += part.shade_launches;
+                stats->batches += part.batches;
+                stats->max_depth_reached = std::max(stats->max_depth_reached, part.max_depth_reached);
+            }
+        }
+        if (rgb8) {
+            rtd::launch_quantize(ctx->tmp_accum.p, npix, spp, ctx->tmp_rgb8.p, ctx->stream);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(rgb8, ctx->tmp_rgb8.p, npix * 3, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (sum_rgb)
+            HIP_CHECK(hipMemcpyAsync(sum_rgb, ctx->tmp_accum.p, npix * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,921 @@
+// gfx950 (MI355X, wave64) kernels of the wavefront path tracer:
+//   raygen  -> [extend -> shade(+compaction)] x bounces -> accumulate -> quantize
+//
+// What each stage replaces in the reference (FBemf/raytracer @ v0):
+//   raygen      src/main.rs:132-135 + Camera::find_ray (src/camera.rs:67-75)
+//   extend      world.hit(ray, 0.001, inf) (src/hitting.rs:21): BVHNode::hit (:211-229),
+//               AABB::intersects (:249-268), Vec<..>::hit (:88-104), the primitives of
+//               src/objects.rs, the instance transforms of src/transforms.rs
+//   shade       Material::emitted / scatter (src/materials.rs), textures (src/textures.rs),
+//               the sky closure (src/config.rs:405-421) and the recursion of cast_ray
+//               (src/hitting.rs:11-31) unrolled into a throughput product
+//   accumulate  `colour += cast_ray(..)` (src/main.rs:136)
+//   quantize    src/main.rs:138-142 + colour_to_raw (:172-177)
+//
+// Compiled with -ffp-contract=off: rustc never contracts a*b+c, and the f64 instantiation
+// follows the reference's operation order so that it walks the same paths as the oracle.
+#include "rt_device.h"
+
+#include "../../../include/rt_mi355x.h"
+
+namespace rtd {
+
+// ------------------------------------------------------------------ small vector algebra
+template <typename T>
+struct V3 {
+    T x, y, z;
+};
+template <typename T> __device__ __forceinline__ V3<T> mk(T x, T y, T z) { return V3<T>{x, y, z}; }
+template <typename T> __device__ __forceinline__ V3<T> ld3(const T* p) { return V3<T>{p[0], p[1], p[2]}; }
+template <typename T> __device__ __forceinline__ V3<T> operator+(V3<T> a, V3<T> b) { return V3<T>{a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator-(V3<T> a, V3<T> b) { return V3<T>{a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator-(V3<T> a) { return V3<T>{-a.x, -a.y, -a.z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator*(V3<T> a, T s) { return V3<T>{a.x * s, a.y * s, a.z * s}; }
+template <typename T> __device__ __forceinline__ V3<T> operator*(T s, V3<T> a) { return V3<T>{a.x * s, a.y * s, a.z * s}; }
+template <typename T> __device__ __forceinline__ V3<T> operator/(V3<T> a, T s) { return V3<T>{a.x / s, a.y / s, a.z / s}; }
+template <typename T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> __device__ __forceinline__ V3<T> cross(V3<T> l, V3<T> r) {
+    return V3<T>{l.y * r.z - l.z * r.y, l.z * r.x - l.x * r.z, l.x * r.y - l.y * r.x};
+}
+template <typename T> __device__ __forceinline__ V3<T> coeff(V3<T> a, V3<T> b) { return V3<T>{a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <typename T> __device__ __forceinline__ T length_squared(V3<T> a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+template <typename T> __device__ __forceinline__ T length(V3<T> a) { return sqrt(length_squared(a)); }
+template <typename T> __device__ __forceinline__ V3<T> unit_vector(V3<T> a) {  // src/math.rs:34-40
+    T l = length(a);
+    return V3<T>{a.x / l, a.y / l, a.z / l};
+}
+template <typename T> __device__ __forceinline__ T comp(V3<T> a, int i) { return i == 0 ? a.x : i == 1 ? a.y : a.z; }
+template <typename T> __device__ __forceinline__ bool near_zero(V3<T> a) {  // src/math.rs:41-44
+    const T d = (T)1e-8;
+    return fabs(a.x) < d && fabs(a.y) < d && fabs(a.z) < d;
+}
+template <typename T> __device__ __forceinline__ V3<T> reflect(V3<T> d, V3<T> n) {  // src/math.rs:67-69
+    return d - ((T)2.0 * dot(d, n)) * n;
+}
+template <typename T> __device__ __forceinline__ V3<T> refract(V3<T> d, V3<T> n, T eta) {  // src/math.rs:71-78
+    d = unit_vector(d);
+    T cos_theta = fmin(dot(-d, n), (T)1.0);
+    V3<T> perp = eta * (d + cos_theta * n);
+    V3<T> par = (-(sqrt(fabs((T)1.0 - length_squared(perp))))) * n;
+    return perp + par;
+}
+template <typename T> struct Lim;
+template <> struct Lim<double> { static __device__ __forceinline__ double inf() { return __longlong_as_double(0x7ff0000000000000LL); } };
+template <> struct Lim<float> { static __device__ __forceinline__ float inf() { return __int_as_float(0x7f800000); } };
+
+template <typename T>
+struct Ray {
+    V3<T> o, d;
+    T time;
+    __device__ __forceinline__ V3<T> at(T t) const { return o + t * d; }  // src/math.rs:215-217
+};
+
+// ------------------------------------------------------------------ random streams
+// Philox4x32-10, keyed as documented in DESIGN.md ("RNG") - the same specification the
+// oracle implements in oracle/philox.hpp (written independently here).
+enum : uint32_t { DOMAIN_CAMERA = 0u, DOMAIN_MATERIAL = 1u, DOMAIN_MEDIUM = 0x80000000u };
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t* out) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <typename T> __device__ __forceinline__ T bits_to_unit(uint64_t x);
+template <> __device__ __forceinline__ double bits_to_unit<double>(uint64_t x) { return (double)(x >> 11) * 0x1.0p-53; }
+template <> __device__ __forceinline__ float bits_to_unit<float>(uint64_t x) { return (float)(x >> 40) * 0x1.0p-24f; }
+
+template <typename T>
+struct Rng {
+    uint32_t k0, k1, pixel, sample, bounce, block;
+    T spare;
+    int have;
+    __device__ __forceinline__ Rng(uint64_t seed, uint32_t domain, uint32_t px, uint32_t smp, uint32_t b)
+        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32) ^ domain), pixel(px), sample(smp), bounce(b), block(0),
+          spare(0), have(0) {}
+    __device__ __forceinline__ T next() {  // uniform in [0, 1)
+        if (have) {
+            have = 0;
+            return spare;
+        }
+        uint32_t r[4];
+        philox4x32_10(pixel, sample, bounce, block, k0, k1, r);
+        block++;
+        spare = bits_to_unit<T>((uint64_t)r[2] | ((uint64_t)r[3] << 32));
+        have = 1;
+        return bits_to_unit<T>((uint64_t)r[0] | ((uint64_t)r[1] << 32));
+    }
+    __device__ __forceinline__ T range(T lo, T hi) { return lo + (hi - lo) * next(); }
+};
+
+template <typename T> __device__ V3<T> random_in_unit_sphere(Rng<T>& rng) {  // src/math.rs:234-246
+    for (;;) {
+        T px = rng.range((T)-1.0, (T)1.0);
+        T py = rng.range((T)-1.0, (T)1.0);
+        T pz = rng.range((T)-1.0, (T)1.0);
+        V3<T> p = mk(px, py, pz);
+        if (length_squared(p) <= (T)1.0) return p;
+    }
+}
+template <typename T> __device__ V3<T> random_in_unit_disc(Rng<T>& rng) {  // src/math.rs:248-256
+    for (;;) {
+        T px = rng.range((T)-1.0, (T)1.0);
+        T py = rng.range((T)-1.0, (T)1.0);
+        V3<T> p = mk(px, py, (T)0.0);
+        if (length_squared(p) <= (T)1.0) return p;
+    }
+}
+
+__device__ __forceinline__ void path_ids(const DBatch& B, uint32_t pid, uint32_t* pixel, uint32_t* sample) {
+    if (B.trace_mode) {
+        *pixel = B.s0 + pid;  // rt_trace: the ray's index in the caller's array
+        *sample = 0;
+    } else {
+        uint32_t pl = pid % B.npix, sl = pid / B.npix;
+        *pixel = B.j0 * B.width + pl;  // (j0 + pl / W) * W + pl % W
+        *sample = B.s0 + sl;
+    }
+}
+
+// ------------------------------------------------------------------ primitives
+template <typename T>
+__device__ __forceinline__ Ray<T> to_object_space(const DXform<T>& X, const Ray<T>& r) {
+    // One rigid map for a whole chain of Translate/Rotate*::hit (src/transforms.rs:22-23,
+    // 103-112, 194-203, 285-294); Ray::new re-normalises the direction (src/math.rs:208-214).
+    Ray<T> q;
+    q.o = mk(X.m[0] * r.o.x + X.m[1] * r.o.y + X.m[2] * r.o.z + X.b[0],
+             X.m[3] * r.o.x + X.m[4] * r.o.y + X.m[5] * r.o.z + X.b[1],
+             X.m[6] * r.o.x + X.m[7] * r.o.y + X.m[8] * r.o.z + X.b[2]);
+    q.d = unit_vector(mk(X.m[0] * r.d.x + X.m[1] * r.d.y + X.m[2] * r.d.z,
+                         X.m[3] * r.d.x + X.m[4] * r.d.y + X.m[5] * r.d.z,
+                         X.m[6] * r.d.x + X.m[7] * r.d.y + X.m[8] * r.d.z));
+    q.time = r.time;
+    return q;
+}
+template <typename T>
+__device__ __forceinline__ V3<T> rotate_to_world(const DXform<T>& X, V3<T> n) {  // m^T n
+    return mk(X.m[0] * n.x + X.m[3] * n.y + X.m[6] * n.z, X.m[1] * n.x + X.m[4] * n.y + X.m[7] * n.z,
+              X.m[2] * n.x + X.m[5] * n.y + X.m[8] * n.z);
+}
+
+template <typename T>
+__device__ __forceinline__ bool distance_to_sphere(const Ray<T>& ray, V3<T> centre, T radius, T min_dist, T max_dist,
+                                                   T* out) {  // src/math.rs:258-286
+    V3<T> oc = ray.o - centre;
+    T a = length_squared(ray.d);
+    T half_b = dot(oc, ray.d);
+    T c = length_squared(oc) - radius * radius;
+    T discriminant = half_b * half_b - a * c;
+    if (discriminant < (T)0.0) return false;
+    T sqrt_d = sqrt(discriminant);
+    T root = (-half_b - sqrt_d) / a;
+    if (root < min_dist || root > max_dist) {
+        root = (-half_b + sqrt_d) / a;
+        if (root < min_dist || root > max_dist) return false;
+    }
+    *out = root;
+    return true;
+}
+
+template <typename T>
+__device__ __forceinline__ V3<T> moving_centre(const DMovingSphere<T>& s, T time) {  // src/objects.rs:94-97
+    return ld3(s.centre0) + ((time - s.time0) / (s.time1 - s.time0)) * (ld3(s.centre1) - ld3(s.centre0));
+}
+
+template <typename T>
+__device__ __forceinline__ bool line_plane_collision(V3<T> la, V3<T> lab, V3<T> p0, V3<T> p01, V3<T> p02, V3<T>* out) {
+    // src/math.rs:298-317 (absolute 1e-7 determinant gate)
+    const T MARGIN = (T)0.0000001;
+    V3<T> cross_p = cross(p01, p02);
+    T determinant = dot(-lab, cross_p);
+    if (determinant < -MARGIN || determinant > MARGIN) {
+        V3<T> w = la - p0;
+        T t = dot(cross_p, w) / determinant;
+        T u = dot(cross(p02, -lab), w) / determinant;
+        T v = dot(cross(-lab, p01), w) / determinant;
+        *out = mk(t, u, v);
+        return true;
+    }
+    return false;
+}
+
+// XYRect / XZRect / YZRect::hit, src/objects.rs:224-244, 288-308, 352-372.
+template <typename T>
+__device__ __forceinline__ bool rect_hit(const DRect<T>& q, const Ray<T>& r, T min_dist, T max_dist, T* t_out) {
+    int axis = q.axis;
+    int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
+    T t = (q.k - comp(r.o, axis)) / comp(r.d, axis);
+    if (t < min_dist || t > max_dist) return false;
+    T a = comp(r.o, ia) + t * comp(r.d, ia);
+    T b = comp(r.o, ib) + t * comp(r.d, ib);
+    if (a < q.a0 || a > q.a1 || b < q.b0 || b > q.b1) return false;
+    if (t != t) return false;  // 0/0: declared deviation, NaN hits are rejected
+    *t_out = t;
+    return true;
+}
+
+// Vec<Arc<dyn Hittable>>::hit over a Block's sides / a Spotlight's panes (src/hitting.rs:88-104):
+// every element sees the same [min,max]; strict < keeps the first of equal distances.
+template <typename T>
+__device__ __forceinline__ bool rects_hit(const DScene<T>& S, const Ray<T>& r, int first, int count, T min_dist,
+                                          T max_dist, T* t_out, int* prim_out) {
+    bool have = false;
+    T bt = 0;
+    int bi = -1;
+    for (int k = 0; k < count; k++) {
+        T t;
+        if (rect_hit(S.rects[first + k], r, min_dist, max_dist, &t)) {
+            if (!have || t < bt) {
+                bt = t;
+                bi = first + k;
+            }
+            have = true;
+        }
+    }
+    *t_out = bt;
+    *prim_out = bi;
+    return have;
+}
+
+template <typename T>
+__device__ __forceinline__ bool triangle_hit(const DTriangle<T>& tr, const Ray<T>& r, T min_dist, T max_dist, T* t_out) {
+    // src/objects.rs:537-558
+    V3<T> s;
+    if (!line_plane_collision(r.o, r.d, ld3(tr.point), ld3(tr.vec1), ld3(tr.vec2), &s)) return false;
+    if (s.x < min_dist || s.x > max_dist) return false;
+    if (s.y < (T)0.0 || s.z < (T)0.0 || s.y + s.z > (T)1.0) return false;
+    *t_out = s.x;
+    return true;
+}
+
+// AABB::intersects, src/hitting.rs:249-268, with the divisions replaced by multiplications
+// with 1/d (identical for the two planes of an axis, so a zero-thickness box still fails
+// the `max <= min` test exactly as in the reference).  fmin/fmax ignore NaN as f64::min/max do.
+template <typename T>
+__device__ __forceinline__ bool box_hit(const DNode<T>& n, V3<T> o, V3<T> inv_d, T min_dist, T max_dist) {
+    T ta = (n.lo[0] - o.x) * inv_d.x, tb = (n.hi[0] - o.x) * inv_d.x;
+    min_dist = fmax(fmin(ta, tb), min_dist);
+    max_dist = fmin(fmax(ta, tb), max_dist);
+    if (max_dist <= min_dist) return false;
+    ta = (n.lo[1] - o.y) * inv_d.y; tb = (n.hi[1] - o.y) * inv_d.y;
+    min_dist = fmax(fmin(ta, tb), min_dist);
+    max_dist = fmin(fmax(ta, tb), max_dist);
+    if (max_dist <= min_dist) return false;
+    ta = (n.lo[2] - o.z) * inv_d.z; tb = (n.hi[2] - o.z) * inv_d.z;
+    min_dist = fmax(fmin(ta, tb), min_dist);
+    max_dist = fmin(fmax(ta, tb), max_dist);
+    if (max_dist <= min_dist) return false;
+    return true;
+}
+
+// Per-lane traversal stack in LDS: entry e of lane l lives at stack[e * BLOCK + l], so the
+// 64 lanes of a wave touch 64 consecutive dwords (no bank conflicts).
+struct Stack {
+    int32_t* base;
+    int stride;
+    __device__ __forceinline__ void put(int e, int32_t v) { base[e * stride] = v; }
+    __device__ __forceinline__ int32_t get(int e) const { return base[e * stride]; }
+};
+
+// BVHNode::hit over a triangle BVH (src/hitting.rs:211-229).  The recursion "left with
+// [min,max], then right with [min, min(left.t, max)], right wins if it hits" is a
+// depth-first walk, left child first, with a shrinking upper bound that accepts t <= bound
+// (so the later leaf wins an exact tie, as in the reference).
+template <typename T>
+__device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, Stack st, int sp0,
+                         T* t_out, int* prim_out) {
+    V3<T> inv_d = mk((T)1.0 / r.d.x, (T)1.0 / r.d.y, (T)1.0 / r.d.z);
+    int sp = sp0;
+    int cur = root;
+    bool found = false;
+    for (;;) {
+        const DNode<T>& n = S.nodes[cur];
+        int left = n.left;
+        if (left < 0) {
+            int tri = -1 - left;
+            T t;
+            if (triangle_hit(S.triangles[tri], r, min_dist, max_dist, &t)) {
+                max_dist = t;
+                *prim_out = tri;
+                found = true;
+            }
+        } else if (box_hit(n, r.o, inv_d, min_dist, max_dist)) {
+            st.put(sp++, n.right);
+            cur = left;
+            continue;
+        }
+        if (sp == sp0) break;
+        cur = st.get(--sp);
+    }
+    *t_out = max_dist;
+    return found;
+}
+
+struct Winner {
+    int obj;   // rt_object index of the instance that was hit (-1: none)
+    int prim;  // index into the array of the object's kind (rect / triangle / ... / medium)
+};
+
+// Hittable::hit of one non-medium object instance with bounds [min_dist, max_dist].
+template <typename T>
+__device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist,
+                                  Stack st, int sp, T* t_out, int* prim_out) {
+    const DObject ob = S.objects[oi];
+    Ray<T> r = world_ray;
+    if (ob.xform >= 0) r = to_object_space(S.xforms[ob.xform], world_ray);
+    switch (ob.kind) {
+        case RT_OBJ_SPHERE: {
+            const DSphere<T>& s = S.spheres[ob.first];
+            *prim_out = ob.first;
+            return distance_to_sphere(r, ld3(s.centre), s.radius, min_dist, max_dist, t_out);
+        }
+        case RT_OBJ_MOVING_SPHERE: {
+            const DMovingSphere<T>& s = S.moving_spheres[ob.first];
+            *prim_out = ob.first;
+            return distance_to_sphere(r, moving_centre(s, r.time), s.radius, min_dist, max_dist, t_out);
+        }
+        case RT_OBJ_RECTS: return rects_hit(S, r, ob.first, ob.count, min_dist, max_dist, t_out, prim_out);
+        case RT_OBJ_TRIANGLE: *prim_out = ob.first; return triangle_hit(S.triangles[ob.first], r, min_dist, max_dist, t_out);
+        case RT_OBJ_PLANE: {  // src/objects.rs:599-606
+            const DPlane<T>& p = S.planes[ob.first];
+            V3<T> s;
+            if (!line_plane_collision(r.o, r.d, ld3(p.point), ld3(p.vec1), ld3(p.vec2), &s)) return false;
+            if (s.x < min_dist || s.x > max_dist) return false;
+            *t_out = s.x;
+            *prim_out = ob.first;
+            return true;
+        }
+        case RT_OBJ_BLAS: return blas_hit(S, r, ob.first, min_dist, max_dist, st, sp, t_out, prim_out);
+        default: return false;
+    }
+}
+
+// Hittable::hit of any object instance, constant media included (src/objects.rs:404-448).
+template <typename T>
+__device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist, Stack st,
+                           int sp, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t depth, T* t_out,
+                           int* prim_out) {
+    const DObject ob = S.objects[oi];
+    if (ob.kind != RT_OBJ_MEDIUM) return simple_object_hit(S, oi, world_ray, min_dist, max_dist, st, sp, t_out, prim_out);
+    const DMedium<T>& md = S.media[ob.first];
+    Ray<T> r = world_ray;
+    if (ob.xform >= 0) r = to_object_space(S.xforms[ob.xform], world_ray);
+    const T inf = Lim<T>::inf();
+    T t1, t2;
+    int ignore;
+    if (!simple_object_hit(S, md.boundary_object, r, -inf, inf, st, sp, &t1, &ignore)) return false;
+    if (!simple_object_hit(S, md.boundary_object, r, t1 + (T)0.0001, inf, st, sp, &t2, &ignore)) return false;
+    if (t1 < min_dist) t1 = min_dist;
+    if (t2 > max_dist) t2 = max_dist;
+    if (t1 >= t2) return false;
+    if (t1 < (T)0.0) t1 = (T)0.0;
+    T ray_length = length(r.d);
+    T distance_inside_boundary = (t2 - t1) * ray_length;
+    Rng<T> rng(seed, DOMAIN_MEDIUM | md.rng_key, pixel, sample, depth);
+    T hit_distance = md.neg_inv_density * log(rng.next());
+    if (hit_distance > distance_inside_boundary) return false;
+    *t_out = t1 + hit_distance / ray_length;
+    *prim_out = ob.first;
+    return true;
+}
+
+// world.hit(ray, min, max): the top-level Vec (src/hitting.rs:188-194 -> :88-104) over the
+// world BVH and the unbounded objects; inside the BVH, BVHNode::hit (:211-229).
+template <typename T>
+__device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T max_dist, Stack st, uint64_t seed,
+                            uint32_t pixel, uint32_t sample, uint32_t depth, T* t_out, Winner* w_out) {
+    bool have = false;
+    T best_t = 0;
+    Winner best{-1, -1};
+    for (int e = 0; e < S.n_top; e++) {
+        int entry = S.top_list[e];
+        bool found = false;
+        T t = 0;
+        Winner w{-1, -1};
+        if (entry != RT_TOP_BVH) {
+            found = object_hit(S, entry, ray, min_dist, max_dist, st, 0, seed, pixel, sample, depth, &t, &w.prim);
+            w.obj = entry;
+        } else {
+            V3<T> inv_d = mk((T)1.0 / ray.d.x, (T)1.0 / ray.d.y, (T)1.0 / ray.d.z);
+            T bound = max_dist;
+            int sp = 0;
+            int cur = S.tlas_root;
+            for (;;) {
+                const DNode<T>& n = S.nodes[cur];
+                int left = n.left;
+                if (left < 0) {
+                    int oi = -1 - left;
+                    T th;
+                    int prim;
+                    if (object_hit(S, oi, ray, min_dist, bound, st, sp, seed, pixel, sample, depth, &th, &prim)) {
+                        bound = th;
+                        w.obj = oi;
+                        w.prim = prim;
+                        found = true;
+                    }
+                } else if (box_hit(n, ray.o, inv_d, min_dist, bound)) {
+                    st.put(sp++, n.right);
+                    cur = left;
+                    continue;
+                }
+                if (sp == 0) break;
+                cur = st.get(--sp);
+            }
+            t = bound;
+        }
+        if (found && (!have || t < best_t)) {
+            best_t = t;
+            best = w;
+            have = true;
+        }
+    }
+    *t_out = best_t;
+    *w_out = best;
+    return have;
+}
+
+template <typename T>
+__device__ __forceinline__ void get_sphere_uv(V3<T> p, T* u, T* v) {  // src/math.rs:288-294
+    const T PI = (T)3.14159265358979323846264338327950288;
+    T theta = acos(-p.y);
+    T phi = atan2(-p.z, p.x) + PI;
+    *u = phi / ((T)2.0 * PI);
+    *v = theta / PI;
+}
+
+template <typename T>
+struct Surface {  // HitRecord, src/hitting.rs:33-41
+    V3<T> normal;
+    T u, v;
+    bool front_face;
+    int material, owner, sub;
+};
+
+// Rebuilds the HitRecord of the winning primitive: outward normal and (u,v) of the
+// primitive, HitRecord::new's face logic (src/hitting.rs:57-79), then the normal rotated
+// back to world space as the Rotate*::hit wrappers do (src/transforms.rs:119-121 etc.).
+template <typename T>
+__device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, T t, Winner w) {
+    const DObject ob = S.objects[w.obj];
+    Ray<T> r = world_ray;
+    if (ob.xform >= 0) r = to_object_space(S.xforms[ob.xform], world_ray);
+    Surface<T> sf;
+    V3<T> outward = mk((T)1.0, (T)0.0, (T)0.0);
+    sf.u = 0;
+    sf.v = 0;
+    sf.sub = 0;
+    bool medium = false;
+    switch (ob.kind) {
+        case RT_OBJ_SPHERE: {
+            const DSphere<T>& s = S.spheres[w.prim];
+            outward = (r.at(t) - ld3(s.centre)) / s.radius;
+            get_sphere_uv(outward, &sf.u, &sf.v);
+            sf.material = s.material;
+            sf.owner = s.owner;
+            break;
+        }
+        case RT_OBJ_MOVING_SPHERE: {
+            const DMovingSphere<T>& s = S.moving_spheres[w.prim];
+            outward = (r.at(t) - moving_centre(s, r.time)) / s.radius;
+            get_sphere_uv(outward, &sf.u, &sf.v);
+            sf.material = s.material;
+            sf.owner = s.owner;
+            break;
+        }
+        case RT_OBJ_RECTS: {
+            const DRect<T>& q = S.rects[w.prim];
+            int axis = q.axis;
+            int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
+            T a = comp(r.o, ia) + t * comp(r.d, ia);
+            T b = comp(r.o, ib) + t * comp(r.d, ib);
+            sf.u = (a - q.a0) / (q.a1 - q.a0);
+            sf.v = (b - q.b0) / (q.b1 - q.b0);
+            T s = q.facing_positive ? (T)1.0 : (T)-1.0;
+            outward = mk(axis == 0 ? s : (T)0.0, axis == 1 ? s : (T)0.0, axis == 2 ? s : (T)0.0);
+            sf.material = q.material;
+            sf.owner = q.owner;
+            sf.sub = q.sub;
+            break;
+        }
+        case RT_OBJ_TRIANGLE:
+        case RT_OBJ_BLAS: {
+            const DTriangle<T>& tr = S.triangles[w.prim];
+            V3<T> s;
+            line_plane_collision(r.o, r.d, ld3(tr.point), ld3(tr.vec1), ld3(tr.vec2), &s);
+            sf.u = s.z;  // (solution[2], solution[1]), src/objects.rs:552
+            sf.v = s.y;
+            outward = ld3(tr.normal);
+            sf.material = tr.material;
+            sf.owner = tr.owner;
+            sf.sub = tr.sub;
+            break;
+        }
+        case RT_OBJ_PLANE: {  // src/objects.rs:607-617
+            const DPlane<T>& p = S.planes[w.prim];
+            V3<T> s;
+            line_plane_collision(r.o, r.d, ld3(p.point), ld3(p.vec1), ld3(p.vec2), &s);
+            T u = fmod(s.y, p.uv_repeat) / p.uv_repeat;
+            T v = fmod(-s.z, p.uv_repeat) / p.uv_repeat;
+            sf.u = u < (T)0.0 ? (T)1.0 + u : u;
+            sf.v = v < (T)0.0 ? (T)1.0 + v : v;
+            outward = ld3(p.normal);
+            sf.material = p.material;
+            sf.owner = p.owner;
+            break;
+        }
+        default: {  // RT_OBJ_MEDIUM: normal (1,0,0), front_face true, uv 0 (src/objects.rs:431-439)
+            const DMedium<T>& md = S.media[w.prim];
+            sf.material = md.material;
+            sf.owner = md.owner;
+            medium = true;
+            break;
+        }
+    }
+    if (medium) {
+        sf.front_face = true;
+        sf.normal = outward;
+    } else {
+        sf.front_face = dot(r.d, outward) < (T)0.0;
+        V3<T> n = unit_vector(outward);
+        sf.normal = sf.front_face ? n : -n;
+    }
+    if (ob.xform >= 0) sf.normal = rotate_to_world(S.xforms[ob.xform], sf.normal);
+    return sf;
+}
+
+// ------------------------------------------------------------------ kernels
+constexpr int BLOCK = 256;
+
+template <typename T>
+__device__ __forceinline__ Ray<T> load_ray(const DQueue<T>& q, uint32_t i) {
+    Ray<T> r;
+    r.o = mk(q.ox[i], q.oy[i], q.oz[i]);
+    r.d = mk(q.dx[i], q.dy[i], q.dz[i]);
+    r.time = q.time[i];
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ void store_ray(const DQueue<T>& q, uint32_t i, const Ray<T>& r) {
+    q.ox[i] = r.o.x; q.oy[i] = r.o.y; q.oz[i] = r.o.z;
+    q.dx[i] = r.d.x; q.dy[i] = r.d.y; q.dz[i] = r.d.z;
+    q.time[i] = r.time;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<T> q, uint32_t n_paths, uint32_t* counts) {
+    uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;
+    if (pid == 0) {
+        counts[0] = n_paths;
+        counts[1] = 0;
+    }
+    if (pid >= n_paths) return;
+    uint32_t pixel, sample;
+    path_ids(B, pid, &pixel, &sample);
+    uint32_t i = pixel % B.width, j = pixel / B.width;
+    Rng<T> rng(B.seed, DOMAIN_CAMERA, pixel, sample, 0);
+    // src/main.rs:132-134
+    T s = ((T)i + rng.range((T)0.0, (T)1.0)) / (T)(B.width - 1);
+    T t = ((T)j + rng.range((T)0.0, (T)1.0)) / (T)(B.height - 1);
+    // Camera::find_ray, src/camera.rs:67-75
+    const DCamera<T>& c = S.camera;
+    V3<T> rd = c.lens_radius * random_in_unit_disc(rng);
+    V3<T> offset = ld3(c.u) * rd.x + ld3(c.v) * rd.y;
+    Ray<T> r;
+    r.o = ld3(c.origin) + offset;
+    r.d = unit_vector(ld3(c.lower_left_corner) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin) - offset);
+    r.time = rng.range(c.start_time, c.end_time);
+    store_ray(q, pid, r);
+    q.tr[pid] = (T)1.0; q.tg[pid] = (T)1.0; q.tb[pid] = (T)1.0;
+    q.pid[pid] = pid;
+}
+
+template <typename T, int STACK>
+__global__ void __launch_bounds__(BLOCK) k_extend(DScene<T> S, DBatch B, DQueue<T> q, DHits<T> h, const T* tmin_arr,
+                                                   const T* tmax_arr, uint32_t depth, const uint32_t* count_in,
+                                                   uint32_t* count_out_to_zero, unsigned long long* ray_total) {
+    __shared__ int32_t lds_stack[STACK * BLOCK];
+    Stack st{lds_stack + threadIdx.x, BLOCK};
+    const uint32_t count = *count_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (count_out_to_zero) *count_out_to_zero = 0;
+        if (ray_total) atomicAdd(ray_total, (unsigned long long)count);
+    }
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        Ray<T> r = load_ray(q, i);
+        uint32_t pid = q.pid[i];
+        uint32_t pixel, sample;
+        path_ids(B, pid, &pixel, &sample);
+        T min_dist = tmin_arr ? tmin_arr[i] : (T)0.001;  // src/hitting.rs:20-21
+        T max_dist = tmax_arr ? tmax_arr[i] : Lim<T>::inf();
+        T t;
+        Winner w;
+        if (closest_hit(S, r, min_dist, max_dist, st, B.seed, pixel, sample, depth, &t, &w)) {
+            Surface<T> sf = make_surface(S, r, t, w);
+            h.t[i] = t;
+            h.nx[i] = sf.normal.x; h.ny[i] = sf.normal.y; h.nz[i] = sf.normal.z;
+            h.u[i] = sf.u; h.v[i] = sf.v;
+            h.mat_front[i] = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
+            if (h.owner) {
+                h.owner[i] = sf.owner;
+                h.sub[i] = sf.sub;
+                h.world_index[i] = S.objects[w.obj].world_index;
+            }
+        } else {
+            h.mat_front[i] = RT_MISS;
+        }
+    }
+}
+
+// Texture::value: SolidColour (src/textures.rs:18-21) / ImageTexture (:39-52).
+template <typename T>
+__device__ __forceinline__ V3<T> texture_value(const DScene<T>& S, const DMaterial<T>& m, T u, T v) {
+    if (m.image < 0) return ld3(m.colour);
+    const DImage im = S.images[m.image];
+    u = u < (T)0.0 ? (T)0.0 : u > (T)1.0 ? (T)1.0 : u;
+    v = (T)1.0 - (v < (T)0.0 ? (T)0.0 : v > (T)1.0 ? (T)1.0 : v);
+    T fi = u * (T)im.width, fj = v * (T)im.height;
+    uint32_t i = fi != fi ? 0u : fi <= (T)0.0 ? 0u : fi >= (T)4294967295.0 ? 4294967295u : (uint32_t)fi;
+    uint32_t j = fj != fj ? 0u : fj <= (T)0.0 ? 0u : fj >= (T)4294967295.0 ? 4294967295u : (uint32_t)fj;
+    i = min(i, (uint32_t)im.width - 1);
+    j = min(j, (uint32_t)im.height - 1);
+    const uint8_t* px = S.texels + im.texel_offset + ((uint64_t)j * (uint32_t)im.width + i) * 3;
+    const T colour_scale = (T)1.0 / (T)255.0;
+    return colour_scale * mk((T)px[0], (T)px[1], (T)px[2]);
+}
+
+template <typename T>
+__device__ __forceinline__ T reflectance(T cosine, T ref_idx) {  // src/materials.rs:107-111 (1.1 as written)
+    T r0 = ((T)1.1 - ref_idx) / ((T)1.0 + ref_idx);
+    r0 = r0 * r0;
+    return r0 + ((T)1.0 - r0) * pow((T)1.0 - cosine, (T)5.0);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_shade(DScene<T> S, DBatch B, DQueue<T> qin, DHits<T> h, DQueue<T> qout,
+                                                  T* sample_rgb, uint32_t depth, uint32_t max_bounces,
+                                                  const uint32_t* count_in, uint32_t* count_out) {
+    const uint32_t count = *count_in;
+    const T PI = (T)3.14159265358979323846264338327950288;
+    const uint32_t lane = threadIdx.x & 63;
+    // The loop bound is wave-uniform so that every lane reaches the ballot below.
+    for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < count; base += gridDim.x * BLOCK) {
+        uint32_t i = base + lane;
+        bool alive = false;
+        Ray<T> nr;
+        V3<T> thr;
+        uint32_t pid = 0;
+        if (i < count) {
+            Ray<T> ray = load_ray(qin, i);
+            pid = qin.pid[i];
+            thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
+            uint32_t mf = h.mat_front[i];
+            V3<T> add = mk((T)0.0, (T)0.0, (T)0.0);
+            bool contributes = false;
+            if (mf == RT_MISS) {  // sky(ray), src/hitting.rs:29
+                V3<T> c;
+                if (S.sky.gradient) {  // src/camera.rs:78-86
+                    T gradient_pos = dot(ld3(S.sky.unit_dir), unit_vector(ray.d));
+                    T t = (T)0.5 * (gradient_pos + (T)1.0);
+                    c = (T)1.0 * (((T)1.0 - t) * ld3(S.sky.colour0) + t * ld3(S.sky.colour1));
+                } else {
+                    c = ld3(S.sky.colour);
+                }
+                add = coeff(thr, c);
+                contributes = true;
+            } else {
+                bool front = (mf & 0x80000000u) != 0;
+                int mi = (int)(mf & 0x7fffffffu);
+                T t = h.t[i], u = h.u[i], v = h.v[i];
+                V3<T> n = mk(h.nx[i], h.ny[i], h.nz[i]);
+                V3<T> p = ray.at(t);  // HitRecord::new: intersection = ray.at(distance)
+                // emitted(): Checkered picks its part with sin(k u) sin(k v) - no PI (src/materials.rs:175-183)
+                {
+                    int me = mi;
+                    DMaterial<T> m = S.materials[me];
+                    while (m.type == RT_MAT_CHECKERED) {
+                        T sines = sin(m.param * u) * sin(m.param * v);
+                        me = sines < (T)0.0 ? m.odd : m.even;
+                        m = S.materials[me];
+                    }
+                    if (m.type == RT_MAT_DIFFUSE_LIGHT && front) {  // src/materials.rs:129-136
+                        add = coeff(thr, texture_value(S, m, u, v));
+                        contributes = true;
+                    }
+                }
+                // scatter(): Checkered picks with sin(k PI u) sin(k PI v) (src/materials.rs:166-174)
+                DMaterial<T> m = S.materials[mi];
+                while (m.type == RT_MAT_CHECKERED) {
+                    T sines = sin(m.param * PI * u) * sin(m.param * PI * v);
+                    mi = sines < (T)0.0 ? m.odd : m.even;
+                    m = S.materials[mi];
+                }
+                uint32_t pixel, sample;
+                path_ids(B, pid, &pixel, &sample);
+                Rng<T> rng(B.seed, DOMAIN_MATERIAL, pixel, sample, depth);
+                V3<T> attenuation = mk((T)1.0, (T)1.0, (T)1.0);
+                V3<T> dir = n;
+                bool scattered = false, metal = false;
+                switch (m.type) {
+                    case RT_MAT_LAMBERTIAN: {  // src/materials.rs:27-42
+                        dir = n + unit_vector(random_in_unit_sphere(rng));
+                        if (near_zero(dir)) dir = n;
+                        attenuation = texture_value(S, m, u, v);
+                        scattered = true;
+                        break;
+                    }
+                    case RT_MAT_METAL: {  // :53-66
+                        V3<T> reflected = reflect(unit_vector(ray.d), n);
+                        dir = reflected + m.param * random_in_unit_sphere(rng);
+                        attenuation = ld3(m.colour);
+                        metal = true;
+                        scattered = true;
+                        break;
+                    }
+                    case RT_MAT_DIELECTRIC: {  // :76-101
+                        T ratio = front ? (T)1.0 / m.param : m.param;
+                        V3<T> ud = unit_vector(ray.d);
+                        T cos_theta = fmin(dot(-ud, n), (T)1.0);
+                        T sin_theta = sqrt((T)1.0 - cos_theta * cos_theta);
+                        bool cannot_refract = ratio * sin_theta > (T)1.0;
+                        T random_fraction = rng.range((T)0.0, (T)1.0);
+                        dir = (cannot_refract || reflectance(cos_theta, ratio) > random_fraction) ? reflect(ud, n)
+                                                                                                 : refract(ud, n, ratio);
+                        scattered = true;
+                        break;
+                    }
+                    case RT_MAT_ISOTROPIC: {  // :146-153
+                        dir = random_in_unit_sphere(rng);
+                        attenuation = texture_value(S, m, u, v);
+                        scattered = true;
+                        break;
+                    }
+                    default: break;  // DiffuseLight::scatter -> None (:126-128)
+                }
+                // cast_ray(new_ray, .., bounces - 1) returns black once bounces hits 0 (src/hitting.rs:17-19).
+                V3<T> new_dir = unit_vector(dir);  // Ray::new normalises (src/math.rs:208-214)
+                if (metal) scattered = dot(new_dir, n) > (T)0.0;  // absorbed otherwise (src/materials.rs:61-65)
+                if (scattered && depth + 1 < max_bounces) {
+                    alive = true;
+                    nr.o = p;
+                    nr.d = new_dir;
+                    nr.time = ray.time;
+                    thr = coeff(thr, attenuation);
+                }
+            }
+            if (contributes) {
+                T* dst = sample_rgb + (uint64_t)pid * 3;
+                dst[0] += add.x; dst[1] += add.y; dst[2] += add.z;
+            }
+        }
+        // Compaction: one atomic per wave, lanes placed by the prefix count of the ballot.
+        unsigned long long mask = __ballot(alive);
+        if (mask) {
+            uint32_t total = (uint32_t)__popcll(mask);
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(count_out, total);
+            start = __shfl(start, 0);
+            if (alive) {
+                uint32_t o = start + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                store_ray(qout, o, nr);
+                qout.tr[o] = thr.x; qout.tg[o] = thr.y; qout.tb[o] = thr.z;
+                qout.pid[o] = pid;
+            }
+        }
+    }
+}
+
+// colour += cast_ray(..) over the samples of a batch, in sample order (src/main.rs:131-137).
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_accumulate(const T* sample_rgb, uint32_t npix, uint32_t n_samples, double* accum) {
+    uint32_t e = blockIdx.x * BLOCK + threadIdx.x;  // element = pixel * 3 + channel
+    if (e >= npix * 3u) return;
+    double acc = accum[e];
+    for (uint32_t s = 0; s < n_samples; s++) acc += (double)sample_rgb[(uint64_t)s * npix * 3u + e];
+    accum[e] = acc;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_quantize(const double* accum, uint64_t n, uint32_t spp_total, uint8_t* rgb8) {
+    uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    double c = accum[e] / (double)spp_total;              // colour /= samples_per_pixel (src/main.rs:138)
+    c = sqrt(c);                                          // gamma 2 (:140-141)
+    c = fabs(c);                                          // colour_to_raw (:172-177)
+    c = c < 0.0 ? 0.0 : c > 0.999 ? 0.999 : c;            // clamp() passes NaN through (src/math.rs:220-228)
+    double f = floor(255.0 * c);
+    rgb8[e] = f != f ? 0 : f <= 0.0 ? 0 : f >= 255.0 ? 255 : (uint8_t)f;  // `as u8`: saturating, NaN -> 0
+}
+
+// rt_trace plumbing: AoS f64 host layout <-> SoA queues.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_load_rays(const double* rays9, uint32_t n, DQueue<T> q, T* tmin, T* tmax, uint32_t* counts) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) {
+        counts[0] = n;
+        counts[1] = 0;
+    }
+    if (i >= n) return;
+    const double* s = rays9 + (uint64_t)i * 9;
+    Ray<T> r;
+    r.o = mk((T)s[0], (T)s[1], (T)s[2]);
+    r.d = unit_vector(mk((T)s[3], (T)s[4], (T)s[5]));  // Ray::new normalises (src/math.rs:208-214)
+    r.time = (T)s[6];
+    store_ray(q, i, r);
+    q.pid[i] = i;
+    tmin[i] = (T)s[7];
+    tmax[i] = (T)s[8];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_store_hits(DQueue<T> q, DHits<T> h, uint32_t n, rt_hit* out) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    rt_hit o;
+    uint32_t mf = h.mat_front[i];
+    if (mf == RT_MISS) {
+        o.hit = 0; o.owner = -1; o.sub = 0; o.world_index = -1; o.front_face = 0; o.material = -1;
+        o.t = 0; o.p[0] = o.p[1] = o.p[2] = 0; o.n[0] = o.n[1] = o.n[2] = 0; o.u = o.v = 0;
+    } else {
+        Ray<T> r = load_ray(q, i);
+        T t = h.t[i];
+        V3<T> p = r.at(t);
+        o.hit = 1;
+        o.owner = h.owner[i]; o.sub = h.sub[i]; o.world_index = h.world_index[i];
+        o.front_face = (mf >> 31) & 1;
+        o.material = (int32_t)(mf & 0x7fffffffu);
+        o.t = (double)t;
+        o.p[0] = (double)p.x; o.p[1] = (double)p.y; o.p[2] = (double)p.z;
+        o.n[0] = (double)h.nx[i]; o.n[1] = (double)h.ny[i]; o.n[2] = (double)h.nz[i];
+        o.u = (double)h.u[i]; o.v = (double)h.v[i];
+    }
+    out[i] = o;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_store_rays(DQueue<T> q, uint32_t n, double* rays9) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double* o = rays9 + (uint64_t)i * 9;
+    o[0] = (double)q.ox[i]; o[1] = (double)q.oy[i]; o[2] = (double)q.oz[i];
+    o[3] = (double)q.dx[i]; o[4] = (double)q.dy[i]; o[5] = (double)q.dz[i];
+    o[6] = (double)q.time[i];
+    o[7] = 0.001;
+    o[8] = (double)Lim<double>::inf();
+}
+
+// ------------------------------------------------------------------ launch wrappers
+static inline int blocks_for(uint64_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
+
+template <typename T>
+void Launch<T>::raygen(const DScene<T>& S, const DBatch& B, DQueue<T> q, uint32_t n_paths, uint32_t* counts, hipStream_t st) {
+    hipLaunchKernelGGL(k_raygen<T>, dim3(blocks_for(n_paths ? n_paths : 1)), dim3(BLOCK), 0, st, S, B, q, n_paths, counts);
+}
+template <typename T>
+void Launch<T>::extend(const DScene<T>& S, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
+                       uint32_t depth, const uint32_t* count_in, uint32_t* count_out_to_zero,
+                       unsigned long long* ray_total, int stack, int grid_blocks, hipStream_t st) {
+    if (stack <= 16)
+        hipLaunchKernelGGL((k_extend<T, 16>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, q, h, tmin, tmax, depth, count_in, count_out_to_zero, ray_total);
+    else if (stack <= 32)
+        hipLaunchKernelGGL((k_extend<T, 32>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, q, h, tmin, tmax, depth, count_in, count_out_to_zero, ray_total);
+    else
+        hipLaunchKernelGGL((k_extend<T, 64>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, q, h, tmin, tmax, depth, count_in, count_out_to_zero, ray_total);
+}
+template <typename T>
+void Launch<T>::shade(const DScene<T>& S, const DBatch& B, DQueue<T> qin, DHits<T> h, DQueue<T> qout, T* sample_rgb,
+                      uint32_t depth, uint32_t max_bounces, const uint32_t* count_in, uint32_t* count_out,
+                      int grid_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_shade<T>, dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, qin, h, qout, sample_rgb, depth, max_bounces, count_in, count_out);
+}
+template <typename T>
+void Launch<T>::accumulate(const T* sample_rgb, uint32_t npix, uint32_t n_samples, double* accum, hipStream_t st) {
+    hipLaunchKernelGGL(k_accumulate<T>, dim3(blocks_for((uint64_t)npix * 3)), dim3(BLOCK), 0, st, sample_rgb, npix, n_samples, accum);
+}
+template <typename T>
+void Launch<T>::load_rays(const double* rays9, uint32_t n, DQueue<T> q, T* tmin, T* tmax, uint32_t* counts, hipStream_t st) {
+    hipLaunchKernelGGL(k_load_rays<T>, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, rays9, n, q, tmin, tmax, counts);
+}
+template <typename T>
+void Launch<T>::store_hits(DQueue<T> q, DHits<T> h, uint32_t n, void* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_store_hits<T>, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, q, h, n, (rt_hit*)out);
+}
+template <typename T>
+void Launch<T>::store_rays(DQueue<T> q, uint32_t n, double* rays9, hipStream_t st) {
+    hipLaunchKernelGGL(k_store_rays<T>, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, q, n, rays9);
+}
+void launch_quantize(const double* accum, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb8, hipStream_t st) {
+    uint64_t n = n_pixels * 3;
+    hipLaunchKernelGGL(k_quantize, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, accum, n, spp_total, rgb8);
+}
+
+template struct Launch<double>;
+template struct Launch<float>;
+
+}  // namespace rtd

@@ -1,0 +1,151 @@
+// Device-side scene layout (HBM-resident SoA) and launch interface of the gfx950 kernels.
+//
+// Everything here is templated on the arithmetic type T: double = the reference's
+// arithmetic (src/math.rs:9-13, every scalar is f64), float = the declared fast mode.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtd {
+
+template <typename T>
+struct alignas(16) DNode {  // f64: 64 B, f32: 32 B - one or two 16 B-aligned vector loads
+    T lo[3], hi[3];
+    int32_t left, right;  // interior: children; leaf: left = -1 - payload, right = RT_LEAF_*
+};
+
+template <typename T>
+struct alignas(16) DXform {  // world -> object: p' = m p + b
+    T m[9], b[3];
+};
+
+template <typename T>
+struct alignas(16) DSphere {
+    T centre[3], radius;
+    int32_t material, owner;
+};
+
+template <typename T>
+struct alignas(16) DMovingSphere {
+    T centre0[3], centre1[3], time0, time1, radius;
+    int32_t material, owner;
+};
+
+template <typename T>
+struct alignas(16) DRect {
+    T a0, a1, b0, b1, k;
+    int32_t axis, facing_positive, material, owner, sub, pad;
+};
+
+template <typename T>
+struct alignas(16) DTriangle {
+    T point[3], vec1[3], vec2[3], normal[3];
+    int32_t material, owner, sub, pad;
+};
+
+template <typename T>
+struct alignas(16) DPlane {
+    T point[3], vec1[3], vec2[3], normal[3], uv_repeat;
+    int32_t material, owner;
+};
+
+template <typename T>
+struct alignas(16) DMedium {
+    T neg_inv_density;
+    int32_t boundary_object, material, owner;
+    uint32_t rng_key;
+};
+
+struct alignas(16) DObject {
+    int32_t kind, xform, first, count;
+    int32_t world_index, pad[3];
+};
+
+template <typename T>
+struct alignas(16) DMaterial {
+    T colour[3], param;
+    int32_t type, image, odd, even;
+};
+
+struct DImage {
+    int32_t width, height;
+    uint64_t texel_offset;
+};
+
+template <typename T>
+struct DCamera {
+    T origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3];
+    T lens_radius, start_time, end_time;
+};
+
+template <typename T>
+struct DSky {
+    int32_t gradient;
+    T colour[3], unit_dir[3], colour0[3], colour1[3];
+};
+
+template <typename T>
+struct DScene {
+    const DNode<T>* nodes;
+    const DObject* objects;
+    const DXform<T>* xforms;
+    const DSphere<T>* spheres;
+    const DMovingSphere<T>* moving_spheres;
+    const DRect<T>* rects;
+    const DTriangle<T>* triangles;
+    const DPlane<T>* planes;
+    const DMedium<T>* media;
+    const DMaterial<T>* materials;
+    const DImage* images;
+    const uint8_t* texels;
+    const int32_t* top_list;
+    int32_t n_top, tlas_root;
+    DCamera<T> camera;
+    DSky<T> sky;
+};
+
+// Ray / path queue: one SoA slab of `capacity` entries per field (coalesced per field).
+template <typename T>
+struct DQueue {
+    T *ox, *oy, *oz, *dx, *dy, *dz, *time;  // Ray (src/math.rs:201-205)
+    T *tr, *tg, *tb;                        // path throughput (product of attenuations)
+    uint32_t* pid;                          // path index inside the batch
+};
+
+// Hit records written by extend, read by shade (HitRecord, src/hitting.rs:33-41).
+template <typename T>
+struct DHits {
+    T *t, *nx, *ny, *nz, *u, *v;
+    uint32_t* mat_front;                    // material | front_face << 31; RT_MISS for a miss
+    int32_t *owner, *sub, *world_index;     // only written when non-null (rt_trace)
+};
+static constexpr uint32_t RT_MISS = 0x7fffffffu;
+
+struct DBatch {      // which pixels / samples the paths of a batch stand for
+    uint32_t width, height, j0, npix;  // npix = width * rows in the band
+    uint32_t s0;                       // first sample index of the batch
+    uint32_t trace_mode;               // 1: rt_trace - pixel = s0 + pid (global ray index), sample = 0
+    uint64_t seed;
+};
+
+// Launch wrappers (kernels.hip).  `stack` selects the LDS traversal-stack depth (16/32/64).
+template <typename T>
+struct Launch {
+    static void raygen(const DScene<T>& S, const DBatch& B, DQueue<T> q, uint32_t n_paths, uint32_t* counts,
+                       hipStream_t st);
+    static void extend(const DScene<T>& S, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
+                       uint32_t depth, const uint32_t* count_in, uint32_t* count_out_to_zero,
+                       unsigned long long* ray_total, int stack, int grid_blocks, hipStream_t st);
+    static void shade(const DScene<T>& S, const DBatch& B, DQueue<T> qin, DHits<T> h, DQueue<T> qout, T* sample_rgb,
+                      uint32_t depth, uint32_t max_bounces, const uint32_t* count_in, uint32_t* count_out,
+                      int grid_blocks, hipStream_t st);
+    static void accumulate(const T* sample_rgb, uint32_t npix, uint32_t n_samples, double* accum, hipStream_t st);
+    static void load_rays(const double* rays9, uint32_t n, DQueue<T> q, T* tmin, T* tmax, uint32_t* counts,
+                          hipStream_t st);
+    static void store_hits(DQueue<T> q, DHits<T> h, uint32_t n, void* out_rt_hit, hipStream_t st);
+    static void store_rays(DQueue<T> q, uint32_t n, double* rays9, hipStream_t st);
+};
+
+void launch_quantize(const double* accum, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb8, hipStream_t st);
+
+}  // namespace rtd
