@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py - whole-job path-tracing throughput on N MI355X of one node.
+
+A "step" is one complete render of the workload (BASELINE.json configs[1]:
+examples/cornell.json5, 600 px wide, 100 samples per pixel PER GPU, 50 bounces) through the
+C ABI of librt_mi355x.so: camera rays -> [extend -> shade/compact] x bounces -> per-pixel
+f64 sums -> reduce to rank 0 (RCCL, N > 1) -> 8-bit rows on rank 0's GPU.  The scene is
+resident in HBM before the timed region.  Weak scaling: every rank traces its own 100
+sample indices of every pixel (rank r: samples [100 r, 100 r + 100)), so N GPUs deliver an
+N x 100 spp image; `value` = closest-hit queries ("rays") of all ranks / time.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (extend = BVH traversal)
+against HBM bandwidth with the algorithmic bytes per ray of DESIGN.md; `cpu_baseline` times
+the CPU oracle (a C++ restatement of the reference's renderer - the Rust reference itself
+cannot be built here) on a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (spec)
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+# Bytes of one record of each flattened array as laid out in HBM (rt_device.h), f64 / f32.
+REC = {
+    "f64": {"ray": 60, "hit": 52, "node": 64, "object": 32, "xform": 96, "rect": 64, "sphere": 48, "triangle": 112, "plane": 128},
+    "f32": {"ray": 32, "hit": 28, "node": 32, "object": 32, "xform": 48, "rect": 48, "sphere": 32, "triangle": 64, "plane": 64},
+}
+PRIM_KIND = {"cornell": "rect", "blocks_ball": "rect", "blue_ball": "rect", "globe": "rect", "two_spheres": "sphere", "knight": "triangle"}
+# flops per box test / primitive test: slab 21, rect 17, sphere 25, triangle 52
+PRIM_FLOPS = {"rect": 17, "sphere": 25, "triangle": 52, "plane": 52}
+
+
+def extend_bytes_per_ray(scene_name: str, prec: str) -> float:
+    """Algorithmic HBM bytes one closest-hit query moves in the extend kernel (DESIGN.md,
+    "Kernels"): the ray read, the hit record written, and every node / object / transform /
+    primitive record the reference traversal touches (means counted by the oracle on the same
+    deterministic BVH, tests/golden/traversal_stats.json)."""
+    with open(os.path.join(ROOT, "tests", "golden", "traversal_stats.json")) as f:
+        st = json.load(f)["scenes"][scene_name]
+    r = REC[prec]
+    prim = r[PRIM_KIND.get(scene_name, "rect")]
+    return (r["ray"] + r["hit"] + st["nodes_per_ray"] * r["node"] + st["leaves_per_ray"] * (r["node"] + r["object"])
+            + st["xforms_per_ray"] * r["xform"] + st["prims_per_ray"] * prim)
+
+
+def extend_flops_per_ray(scene_name: str) -> float:
+    with open(os.path.join(ROOT, "tests", "golden", "traversal_stats.json")) as f:
+        st = json.load(f)["scenes"][scene_name]
+    return st["nodes_per_ray"] * 21 + st["prims_per_ray"] * PRIM_FLOPS[PRIM_KIND.get(scene_name, "rect")] + st["xforms_per_ray"] * 40
+
+
+def cpu_baseline(scene_path: str, width: int, bounces: int, seed: int) -> dict:
+    """CPU oracle on a bounded sample of the workload: same scene / width / bounces, fewer
+    samples per pixel (rays per sample are the same in expectation)."""
+    from oracle import binding as orc
+
+    threads = max(1, min(16, os.cpu_count() or 1))
+    sc = orc.OracleScene.load(scene_path, ROOT)
+    H = sc.image_height(width)
+    spp = 1
+    t0 = time.time()
+    _, _, rays = sc.render(width, H, 0, H, spp, bounces, seed, threads=threads)
+    dt = time.time() - t0
+    # Scale the sample so that it is about 20 s of CPU work (thread-seconds), at most 16 spp.
+    spp2 = int(max(1, min(16, round(20.0 / max(dt * threads, 1e-3)))))
+    t0 = time.time()
+    _, _, rays = sc.render(width, H, 0, H, spp2, bounces, seed, threads=threads)
+    dt = time.time() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{os.path.basename(scene_path)} {width}x{H}, {spp2} spp of the workload's samples, {bounces} bounces, "
+                      f"{rays} rays in {dt:.2f} s; C++ f64 restatement of the reference renderer (oracle/), {threads} threads"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--width", type=int, default=600)
+    ap.add_argument("--spp", type=int, default=100, help="samples per pixel per GPU")
+    ap.add_argument("--bounces", type=int, default=50)
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import raytracer_amd as rt
+    from raytracer_amd import parallel
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    scene_path = os.path.join(ROOT, "examples", args.scene + ".json5")
+    if args.scene == "knight":
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import gen_knight
+
+        gen_knight.ensure(os.path.join(ROOT, "examples", "knight.obj"))
+    scene = rt.Scene.load(scene_path, ROOT)
+    W = args.width
+    H = scene.image_height(W)
+    npix = W * H
+    renderer = rt.Renderer(device=local_rank, precision=rt.PRECISION_F64 if args.precision == "f64" else rt.PRECISION_F32,
+                           max_paths=1 << 26)
+    renderer.upload(scene)
+
+    dev = torch.device("cuda", local_rank)
+    accum = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
+    rgb8 = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
+    total_spp = args.spp * world
+    s0, ns = parallel.split_samples(total_spp, world, rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(collect):
+        accum.zero_()
+        torch.cuda.synchronize()  # torch's stream -> the library's stream hand-off
+        st = renderer.render_accum_device(W, H, 0, H, s0, ns, args.bounces, args.seed, accum.data_ptr(), want_stats=True)
+        parallel.reduce_to_root(accum, dist)
+        if rank == 0:
+            torch.cuda.synchronize()
+            renderer.quantize_device(accum.data_ptr(), npix, total_spp, rgb8.data_ptr())
+        if collect is not None:
+            collect.append(st)
+
+    for _ in range(args.warmup):
+        step(None)
+    stats = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(stats)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    rays = sum(s.rays for s in stats)
+    t = torch.tensor([dt, float(rays), sum(s.ms_extend for s in stats), float(sum(s.extend_launches for s in stats)),
+                      sum(s.ms_shade for s in stats), sum(s.ms_total for s in stats)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        rays_all = float(tsum[1])
+    else:
+        rays_all = float(rays)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_extend, n_extend = float(t[2]), float(t[3])
+    bpr = extend_bytes_per_ray(args.scene, args.precision)
+    # rank 0's own extend launches: bytes per launch / mean launch duration
+    bytes_per_launch = bpr * rays / max(n_extend, 1.0)
+    ms_per_launch = ms_extend / max(n_extend, 1.0)
+    achieved_gbs = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+    flops = extend_flops_per_ray(args.scene) * rays / (ms_extend * 1e-3) / 1e12 if ms_extend > 0 else 0.0
+    valu_peak = FP64_VALU_PEAK_TFLOPS if args.precision == "f64" else FP32_VALU_PEAK_TFLOPS
+    out = {
+        "metric": "Mrays/sec (whole node)",
+        "value": rays_all / dt / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.precision,
+        "data": "synthetic" if args.scene == "knight" else "reference example scene",
+        "config": {
+            "workload": f"examples/{args.scene}.json5 {W}x{H}, {args.spp} spp per GPU ({total_spp} spp image), "
+                        f"{args.bounces} bounces, sample-split across {world} GPU(s), reduce to rank 0, quantise",
+            "paths_per_step": npix * total_spp, "rays_per_step": rays_all / args.steps,
+            "wall_clock_per_image_s": dt / args.steps, "seed": args.seed,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_extend", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_ray": bpr, "launches": n_extend, "avg_launch_ms": ms_per_launch,
+            "note": "scene fits in L2 / Infinity Cache; the VALU side is in roofline_valu",
+        },
+        "roofline_valu": {"kernel": "k_extend", "achieved": flops, "peak": valu_peak, "unit": "TFLOP/s", "frac": flops / valu_peak},
+        "stage_ms_per_step": {"extend": ms_extend / args.steps, "shade": float(t[4]) / args.steps, "gpu_total": float(t[5]) / args.steps},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scene_path, W, args.bounces, args.seed)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,9 +101,10 @@ class OracleScene:
         return rgb8, sums, int(rays)
 
     def traversal_stats(self, width, height, spp, max_bounces, seed=0, pixel_stride=1):
-        out = np.zeros(3)
+        out = np.zeros(5)
         lib().orc_traversal_stats(self._h, width, height, spp, max_bounces, seed, pixel_stride, out.ctypes.data)
-        return {"rays": out[0], "nodes_per_ray": out[1], "prims_per_ray": out[2]}
+        return {"rays": float(out[0]), "nodes_per_ray": float(out[1]), "prims_per_ray": float(out[2]),
+                "leaves_per_ray": float(out[3]), "xforms_per_ray": float(out[4])}
 
     def close(self):
         if self._h:
@@ -119,19 +120,22 @@ class OracleScene:
 
 def cross(a, b):
     out = np.zeros(3)
-    lib().orc_kat_cross(_v3(a).ctypes.data, _v3(b).ctypes.data, out.ctypes.data)
+    a, b = _v3(a), _v3(b)  # keep the temporaries alive across the call
+    lib().orc_kat_cross(a.ctypes.data, b.ctypes.data, out.ctypes.data)
     return out
 
 
 def refract(d, n, eta):
     out = np.zeros(3)
-    lib().orc_kat_refract(_v3(d).ctypes.data, _v3(n).ctypes.data, float(eta), out.ctypes.data)
+    d, n = _v3(d), _v3(n)
+    lib().orc_kat_refract(d.ctypes.data, n.ctypes.data, float(eta), out.ctypes.data)
     return out
 
 
 def reflect(d, n):
     out = np.zeros(3)
-    lib().orc_kat_reflect(_v3(d).ctypes.data, _v3(n).ctypes.data, out.ctypes.data)
+    d, n = _v3(d), _v3(n)
+    lib().orc_kat_reflect(d.ctypes.data, n.ctypes.data, out.ctypes.data)
     return out
 
 
@@ -150,7 +154,8 @@ def unit_vectors(seed, n):
 
 def colour_to_raw(c):
     out = np.zeros(3, dtype=np.uint8)
-    lib().orc_kat_colour_to_raw(_v3(c).ctypes.data, out.ctypes.data)
+    c = _v3(c)
+    lib().orc_kat_colour_to_raw(c.ctypes.data, out.ctypes.data)
     return out
 
 

@@ -113,7 +113,7 @@ struct PathRng {
 static thread_local PathRng tl_rng;
 
 struct Counters {
-    uint64_t rays = 0, nodes = 0, prims = 0;
+    uint64_t rays = 0, nodes = 0, prims = 0, leaves = 0, xforms = 0;
 };
 static thread_local Counters tl_count;
 
@@ -123,6 +123,10 @@ struct Candidate {
 };
 static thread_local std::vector<Candidate>* tl_cands = nullptr;
 static thread_local int tl_cand_mute = 0;
+// Tie detection only (orc_trace's second pass): walk every BVH node the ray's line pierces,
+// without the shrinking upper bound, so that a candidate is never hidden by a box that the
+// `max_dist <= min_dist` rule culls because it starts exactly at the current best distance.
+static thread_local bool tl_exhaustive = false;
 static inline void note_candidate(double t, double min_dist, int owner, int sub) {
     if (tl_cands && !tl_cand_mute && t >= min_dist && t == t) tl_cands->push_back({t, owner, sub});
 }
@@ -388,6 +392,14 @@ struct BVHNode : Hittable {  // :141-240
     AABB bbox;
     bool hit(const Ray& ray, double min_dist, double max_dist, HitRecord* out) const override {  // :212-229
         tl_count.nodes++;
+        if (tl_exhaustive) {
+            if (!bbox.intersects(ray, min_dist, INF)) return false;
+            HitRecord hl, hr;
+            bool l = left->hit(ray, min_dist, INF, &hl), r = right->hit(ray, min_dist, INF, &hr);
+            if (l && (!r || hl.distance < hr.distance)) *out = hl;
+            else if (r) *out = hr;
+            return l || r;
+        }
         if (!bbox.intersects(ray, min_dist, max_dist)) return false;
         HitRecord hit_left;
         if (left->hit(ray, min_dist, max_dist, &hit_left)) {
@@ -849,7 +861,10 @@ static HittablePtr make_spotlight(Point3 looking_from, Point3 looking_at, double
 struct WorldEntry : Hittable {
     HittablePtr inner;
     int index;
+    bool has_xform = false;
     bool hit(const Ray& ray, double min_dist, double max_dist, HitRecord* out) const override {
+        tl_count.leaves++;
+        if (has_xform) tl_count.xforms++;
         if (!inner->hit(ray, min_dist, max_dist, out)) return false;
         out->world_index = index;
         return true;
@@ -1094,6 +1109,11 @@ static OracleScene* build_scene(rt::Scene&& cfg_in) {
         auto e = std::make_shared<WorldEntry>();
         e->inner = S->objects[(size_t)cfg.world[k]];
         e->index = (int)k;
+        {
+            rt::ObjectDef::Type ty = cfg.objects[(size_t)cfg.world[k]].type;
+            e->has_xform = ty == rt::ObjectDef::Translate || ty == rt::ObjectDef::RotateX || ty == rt::ObjectDef::RotateY ||
+                           ty == rt::ObjectDef::RotateZ || ty == rt::ObjectDef::Spotlight;
+        }
         world.push_back(e);
     }
     S->world = bvh_from_vec(world, cfg.camera.start_time, cfg.camera.end_time);
@@ -1171,11 +1191,19 @@ void orc_trace(void* sv, const orc_ray* rays, uint64_t n, uint64_t seed, orc_hit
         tl_rng.begin_path(seed, (uint32_t)i, 0);
         tl_rng.begin_bounce(0);
         tl_count = Counters();
-        cands.clear();
-        tl_cands = &cands;
         HitRecord h;
         bool ok = S->world->hit(r, rays[i].tmin, rays[i].tmax, &h);
-        tl_cands = nullptr;
+        Counters counted = tl_count;
+        if (ok) {  // second pass: every candidate primitive along the ray, for the tie rule
+            cands.clear();
+            tl_cands = &cands;
+            tl_exhaustive = true;
+            HitRecord ignore;
+            (void)S->world->hit(r, rays[i].tmin, INF, &ignore);
+            tl_exhaustive = false;
+            tl_cands = nullptr;
+        }
+        tl_count = counted;
         orc_hit& o = out[i];
         std::memset(&o, 0, sizeof(o));
         o.hit = ok ? 1 : 0;
@@ -1265,7 +1293,7 @@ uint64_t orc_render(void* sv, uint32_t W, uint32_t H, uint32_t j0, uint32_t j1, 
 
 // Mean nodes visited / primitives tested per world.hit over a render (single thread).
 void orc_traversal_stats(void* sv, uint32_t W, uint32_t H, uint32_t spp, uint32_t max_bounces, uint64_t seed,
-                         uint32_t pixel_stride, double* out3) {
+                         uint32_t pixel_stride, double* out5) {
     OracleScene* S = (OracleScene*)sv;
     tl_count = Counters();
     for (uint32_t j = 0; j < H; j += pixel_stride)
@@ -1277,9 +1305,12 @@ void orc_traversal_stats(void* sv, uint32_t W, uint32_t H, uint32_t spp, uint32_
                 Ray r = S->camera.find_ray(u, v, tl_rng.camera);
                 (void)cast_ray(r, *S->world, S->sky, max_bounces, 0);
             }
-    out3[0] = (double)tl_count.rays;
-    out3[1] = tl_count.rays ? (double)tl_count.nodes / (double)tl_count.rays : 0.0;
-    out3[2] = tl_count.rays ? (double)tl_count.prims / (double)tl_count.rays : 0.0;
+    double r = tl_count.rays ? (double)tl_count.rays : 1.0;
+    out5[0] = (double)tl_count.rays;
+    out5[1] = (double)tl_count.nodes / r;   // interior BVH nodes box-tested per ray
+    out5[2] = (double)tl_count.prims / r;   // primitive hit() calls per ray
+    out5[3] = (double)tl_count.leaves / r;  // world-BVH leaves (object instances) visited per ray
+    out5[4] = (double)tl_count.xforms / r;  // of which behind a transform chain
 }
 
 // ---- known-answer hooks for the reference's own unit tests (src/math.rs:319-356)

@@ -80,6 +80,25 @@ EXPORTS = [
 _lib = None
 
 
+def _share_torch_hip_runtime() -> None:
+    """PyTorch wheels bundle their own libamdhip64.so (soname libamdhip64.so.7).  If this
+    library pulled in /opt/rocm's copy first, a later `import torch` would load a second HIP
+    runtime into the process and find no GPU.  Loading torch's copy first (no torch import
+    needed) makes both share one runtime whatever the import order; without torch installed
+    the system runtime is used."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load_library() -> C.CDLL:
     """Loads librt_mi355x.so (built in-tree by `make` / __graft_entry__.build())."""
     global _lib
@@ -89,6 +108,7 @@ def load_library() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make` (hipcc, gfx950). There is no fallback path."
         )
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, restype, argtypes in EXPORTS:
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol

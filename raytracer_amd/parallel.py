@@ -1,0 +1,52 @@
+"""Sample partitioning across GPUs and the reduce of partial radiance sums.
+
+Replaces the rayon row loop of the reference (src/main.rs:117-154: `into_par_iter` over
+rows) at node scale: every rank (one process per GPU) traces a disjoint range of sample
+indices of every pixel, the per-pixel f64 radiance sums are combined with ONE reduce to
+rank 0 (torch.distributed: backend "nccl" = RCCL over xGMI on GPUs, "gloo" in the CPU
+tests), and rank 0 quantises.  Because the random streams are keyed by (pixel, sample
+index, bounce), the reduced image does not depend on the number of ranks beyond f64
+summation order.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+
+def split_samples(total_samples: int, world_size: int, rank: int, first_sample: int = 0) -> Tuple[int, int]:
+    """Contiguous, balanced ranges: returns (s0, n) for `rank`; ranges cover
+    [first_sample, first_sample + total_samples) exactly once; the first
+    total_samples % world_size ranks take one extra sample."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad rank / world_size")
+    if total_samples < 0:
+        raise ValueError("negative sample count")
+    base, extra = divmod(total_samples, world_size)
+    n = base + (1 if rank < extra else 0)
+    s0 = first_sample + rank * base + min(rank, extra)
+    return s0, n
+
+
+def split_rows(height: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Row-band fallback for renders with fewer samples than ranks: (j0, j1) of `rank`."""
+    base, extra = divmod(height, world_size)
+    j0 = rank * base + min(rank, extra)
+    return j0, j0 + base + (1 if rank < extra else 0)
+
+
+def reduce_to_root(accum, dist=None, root: int = 0):
+    """Sums the per-rank accumulation tensors onto `root` (in place).  `dist` is the
+    torch.distributed module of an initialised process group, or None for one rank."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(accum, dst=root, op=dist.ReduceOp.SUM)
+    return accum
+
+
+def render_distributed(render_range: Callable[[int, int], "object"], total_samples: int, rank: int,
+                       world_size: int, dist=None, first_sample: int = 0):
+    """render_range(s0, n) -> tensor of per-pixel radiance SUMS over samples [s0, s0+n).
+    Returns the reduced tensor (meaningful on rank 0) and this rank's (s0, n)."""
+    s0, n = split_samples(total_samples, world_size, rank, first_sample)
+    accum = render_range(s0, n)
+    reduce_to_root(accum, dist)
+    return accum, (s0, n)
