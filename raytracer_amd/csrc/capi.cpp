@@ -227,7 +227,7 @@ struct Engine : EngineBase {
     DevBuf<T> qslab[2], hslab, sample_rgb, tminmax;
     DevBuf<uint32_t> qpid[2], hmat;
     DevBuf<int32_t> hids;
-    DevBuf<uint32_t> counts;
+    DevBuf<uint32_t> counts, tile_counts[2], tile_offsets;
     DevBuf<unsigned long long> ray_total;
     DevBuf<double> io_f64;
     DevBuf<rt_hit> io_hits;
@@ -388,6 +388,8 @@ struct Engine : EngineBase {
             }
             hslab.ensure(n * 6);
             hmat.ensure(n);
+            for (int k = 0; k < 2; k++) tile_counts[k].ensure((n + RT_TILE - 1) / RT_TILE);
+            tile_offsets.ensure((n + RT_TILE - 1) / RT_TILE + 1);
             capacity = n;
         }
         if (with_ids) {
@@ -411,7 +413,8 @@ struct Engine : EngineBase {
         }
         return h;
     }
-    int grid_for(size_t n) {
+    static uint32_t tiles_for(size_t n) { return (uint32_t)((n + RT_TILE - 1) / RT_TILE); }
+    int grid_for(size_t n) {  // persistent blocks, grid-stride over the dense work index
         size_t blocks = (n + 255) / 256;
         size_t cap = (size_t)num_cus * 8;
         return (int)(blocks < 1 ? 1 : blocks > cap ? cap : blocks);
@@ -435,8 +438,9 @@ struct Engine : EngineBase {
             rtd::DHits<T> h = hits(true);
             T* tmin = tminmax.p;
             T* tmax = tminmax.p + capacity;
-            rtd::Launch<T>::load_rays(io_f64.p, (uint32_t)m, q, tmin, tmax, counts.p, stream);
-            rtd::Launch<T>::extend(S, B, q, h, tmin, tmax, 0, counts.p, nullptr, nullptr, stack_depth, grid_for(m), stream);
+            rtd::Launch<T>::load_rays(io_f64.p, (uint32_t)m, q, tmin, tmax, tile_counts[0].p, stream);
+            rtd::launch_scan_tiles(tile_counts[0].p, tiles_for(m), tile_offsets.p, nullptr, counts.p, nullptr, stream);
+            rtd::Launch<T>::extend(S, B, q, h, tmin, tmax, 0, tile_offsets.p, tiles_for(m), stack_depth, grid_for(m), stream);
             rtd::Launch<T>::store_hits(q, h, (uint32_t)m, io_hits.p, stream);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipMemcpyAsync(out + base, io_hits.p, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
@@ -453,7 +457,7 @@ struct Engine : EngineBase {
         io_f64.ensure(n * 9);
         rtd::DBatch B{W, H, j0, (uint32_t)n, sample, 0u, seed};
         rtd::DQueue<T> q = queue(0);
-        rtd::Launch<T>::raygen(S, B, q, (uint32_t)n, counts.p, stream);
+        rtd::Launch<T>::raygen(S, B, q, (uint32_t)n, tile_counts[0].p, stream);
         rtd::Launch<T>::store_rays(q, (uint32_t)n, io_f64.p, stream);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(out, io_f64.p, n * sizeof(rt_ray), hipMemcpyDeviceToHost, stream));
@@ -495,28 +499,35 @@ struct Engine : EngineBase {
             uint32_t n_paths = (uint32_t)(npix * bns);
             rtd::DBatch B{W, H, j0, (uint32_t)npix, bs0, 0u, seed};
             HIP_CHECK(hipMemsetAsync(sample_rgb.p, 0, (size_t)n_paths * 3 * sizeof(T), stream));
-            rtd::Launch<T>::raygen(S, B, queue(0), n_paths, counts.p, stream);
+            rtd::Launch<T>::raygen(S, B, queue(0), n_paths, tile_counts[0].p, stream);
             int grid = grid_for(n_paths);
+            uint32_t n_tiles = tiles_for(n_paths);
+            // offsets of queue 0, clear the counts of queue 1, rays += n_paths (if any bounce runs)
+            rtd::launch_scan_tiles(tile_counts[0].p, n_tiles, tile_offsets.p, tile_counts[1].p, counts.p,
+                                   max_bounces ? ray_total.p : nullptr, stream);
             for (uint32_t depth = 0; depth < max_bounces; depth++) {
                 int in = depth & 1, out = in ^ 1;
                 if (timing) {
                     spans.push_back({ev, 0});
                     HIP_CHECK(hipEventRecord(event(ev), stream));
                 }
-                rtd::Launch<T>::extend(S, B, queue(in), hits(false), nullptr, nullptr, depth, counts.p + in, counts.p + out,
-                                       ray_total.p, stack_depth, grid, stream);
+                rtd::Launch<T>::extend(S, B, queue(in), hits(false), nullptr, nullptr, depth, tile_offsets.p, n_tiles,
+                                       stack_depth, grid, stream);
                 if (timing) {
                     HIP_CHECK(hipEventRecord(event(ev + 1), stream));
                     spans.push_back({ev + 1, 1});
                 }
                 rtd::Launch<T>::shade(S, B, queue(in), hits(false), queue(out), sample_rgb.p, depth, max_bounces,
-                                      counts.p + in, counts.p + out, grid, stream);
+                                      tile_offsets.p, tile_counts[out].p, n_tiles, grid, stream);
+                // offsets of the queue just written, clear the counts of the other one, rays += survivors
+                rtd::launch_scan_tiles(tile_counts[out].p, n_tiles, tile_offsets.p, tile_counts[in].p, counts.p,
+                                       ray_total.p, stream);
                 if (timing) HIP_CHECK(hipEventRecord(event(ev + 2), stream));
                 ev += 3;
                 deepest = std::max(deepest, depth + 1);
                 if ((depth & 3) == 3 && depth + 1 < max_bounces) {
                     // Every 4th bounce: is anything still alive?  (One 4-byte read-back.)
-                    HIP_CHECK(hipMemcpyAsync(host_counts, counts.p + out, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipMemcpyAsync(host_counts, counts.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                     HIP_CHECK(hipStreamSynchronize(stream));
                     if (host_counts[0] == 0) break;
                 }

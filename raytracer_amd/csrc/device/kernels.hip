@@ -79,10 +79,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k1, uint32_t* out) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        // one v_mad_u64_u32 per product (hi and lo together) instead of v_mul_hi + v_mul_lo
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
@@ -553,6 +554,9 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
 
 // ------------------------------------------------------------------ kernels
 constexpr int BLOCK = 256;
+// Paths live in fixed tiles of TILE queue slots; tile t of the output queue receives the
+// survivors of tile t of the input queue, packed at its front, and a per-tile count.
+constexpr uint32_t TILE = RT_TILE;
 
 template <typename T>
 __device__ __forceinline__ Ray<T> load_ray(const DQueue<T>& q, uint32_t i) {
@@ -569,14 +573,67 @@ __device__ __forceinline__ void store_ray(const DQueue<T>& q, uint32_t i, const 
     q.time[i] = r.time;
 }
 
-template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<T> q, uint32_t n_paths, uint32_t* counts) {
-    uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;
-    if (pid == 0) {
-        counts[0] = n_paths;
-        counts[1] = 0;
+
+// Dense work index -> queue slot.  Live entries are packed at the front of each tile;
+// tile_offsets is the exclusive prefix sum of the per-tile counts (tile_offsets[n_tiles] =
+// total), so work item d lives in the tile t with offsets[t] <= d < offsets[t+1].  The tile of
+// a wave's first item is found once per wave by a (scalar) binary search; the other lanes
+// step forward from it.
+__device__ __forceinline__ uint32_t slot_of(const uint32_t* __restrict__ offsets, uint32_t n_tiles, uint32_t d,
+                                            uint32_t d_first, uint32_t* tile_out) {
+    uint32_t d0 = __builtin_amdgcn_readfirstlane(d_first);
+    uint32_t lo = 0, hi = n_tiles;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= d0) lo = mid; else hi = mid;
     }
+    uint32_t tile = lo;
+    while (d >= offsets[tile + 1]) tile++;
+    *tile_out = tile;
+    return tile * TILE + (d - offsets[tile]);
+}
+
+// One block: exclusive scan of the per-tile counts of the queue that is read next; also
+// clears the counts of the queue that is written next and keeps the global totals.
+constexpr int SCAN_THREADS = 1024;
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_tiles(const uint32_t* __restrict__ tile_counts, uint32_t n_tiles,
+                                                              uint32_t* __restrict__ tile_offsets,
+                                                              uint32_t* __restrict__ counts_to_zero,
+                                                              uint32_t* __restrict__ total_out,
+                                                              unsigned long long* __restrict__ ray_total) {
+    __shared__ uint32_t partial[SCAN_THREADS];
+    const uint32_t per = (n_tiles + SCAN_THREADS - 1) / SCAN_THREADS;
+    const uint32_t begin = min(n_tiles, threadIdx.x * per), end = min(n_tiles, begin + per);
+    uint32_t sum = 0;
+    for (uint32_t t = begin; t < end; t++) sum += tile_counts[t];
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t v = threadIdx.x >= (uint32_t)off ? partial[threadIdx.x - off] : 0u;
+        __syncthreads();
+        partial[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = partial[threadIdx.x] - sum;  // exclusive prefix of this thread's segment
+    for (uint32_t t = begin; t < end; t++) {
+        tile_offsets[t] = run;
+        run += tile_counts[t];
+        if (counts_to_zero) counts_to_zero[t] = 0;
+    }
+    if (threadIdx.x == SCAN_THREADS - 1) {
+        uint32_t total = partial[SCAN_THREADS - 1];
+        tile_offsets[n_tiles] = total;
+        *total_out = total;
+        if (ray_total) *ray_total += total;  // every live entry becomes one closest-hit query
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<T> q, uint32_t n_paths,
+                                                   uint32_t* tile_counts) {
+    uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;
     if (pid >= n_paths) return;
+    if (pid % TILE == 0) tile_counts[pid / TILE] = min(TILE, n_paths - pid);
     uint32_t pixel, sample;
     path_ids(B, pid, &pixel, &sample);
     uint32_t i = pixel % B.width, j = pixel / B.width;
@@ -599,16 +656,17 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<
 
 template <typename T, int STACK>
 __global__ void __launch_bounds__(BLOCK) k_extend(DScene<T> S, DBatch B, DQueue<T> q, DHits<T> h, const T* tmin_arr,
-                                                   const T* tmax_arr, uint32_t depth, const uint32_t* count_in,
-                                                   uint32_t* count_out_to_zero, unsigned long long* ray_total) {
+                                                   const T* tmax_arr, uint32_t depth,
+                                                   const uint32_t* __restrict__ tile_offsets, uint32_t n_tiles) {
     __shared__ int32_t lds_stack[STACK * BLOCK];
     Stack st{lds_stack + threadIdx.x, BLOCK};
-    const uint32_t count = *count_in;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (count_out_to_zero) *count_out_to_zero = 0;
-        if (ray_total) atomicAdd(ray_total, (unsigned long long)count);
-    }
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+    const uint32_t total = tile_offsets[n_tiles];
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < total; base += gridDim.x * BLOCK) {
+        const uint32_t d = base + lane;
+        if (d >= total) continue;
+        uint32_t tile;
+        const uint32_t i = slot_of(tile_offsets, n_tiles, d, base, &tile);
         Ray<T> r = load_ray(q, i);
         uint32_t pid = q.pid[i];
         uint32_t pixel, sample;
@@ -661,18 +719,22 @@ __device__ __forceinline__ T reflectance(T cosine, T ref_idx) {  // src/material
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_shade(DScene<T> S, DBatch B, DQueue<T> qin, DHits<T> h, DQueue<T> qout,
                                                   T* sample_rgb, uint32_t depth, uint32_t max_bounces,
-                                                  const uint32_t* count_in, uint32_t* count_out) {
-    const uint32_t count = *count_in;
+                                                  const uint32_t* __restrict__ tile_offsets, uint32_t* tile_counts_out,
+                                                  uint32_t n_tiles) {
     const T PI = (T)3.14159265358979323846264338327950288;
     const uint32_t lane = threadIdx.x & 63;
-    // The loop bound is wave-uniform so that every lane reaches the ballot below.
-    for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < count; base += gridDim.x * BLOCK) {
-        uint32_t i = base + lane;
+    const uint32_t total = tile_offsets[n_tiles];
+    // The loop bound is wave-uniform so that every lane reaches the ballots below.
+    for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < total; base += gridDim.x * BLOCK) {
+        const uint32_t d = base + lane;
+        const bool valid = d < total;
+        uint32_t tile = 0;
+        const uint32_t i = valid ? slot_of(tile_offsets, n_tiles, d, base, &tile) : 0u;
         bool alive = false;
         Ray<T> nr;
         V3<T> thr;
         uint32_t pid = 0;
-        if (i < count) {
+        if (valid) {
             Ray<T> ray = load_ray(qin, i);
             pid = qin.pid[i];
             thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
@@ -775,19 +837,25 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene<T> S, DBatch B, DQueue<T
                 dst[0] += add.x; dst[1] += add.y; dst[2] += add.z;
             }
         }
-        // Compaction: one atomic per wave, lanes placed by the prefix count of the ballot.
-        unsigned long long mask = __ballot(alive);
-        if (mask) {
-            uint32_t total = (uint32_t)__popcll(mask);
+        // Compaction: the survivors of input tile t are packed at the front of output tile t.
+        // One returning atomic per wave and tile on that tile's own counter (thousands of counters
+        // spread over the L2 channels; a single global counter saturates at ~90 atomics/us on
+        // MI355X).  A wave's items span one tile, rarely two; lanes are placed by ballot prefix.
+        unsigned long long todo = __ballot(alive);
+        while (todo) {
+            int leader = __ffsll((long long)todo) - 1;
+            uint32_t t_lead = __shfl(tile, leader);
+            unsigned long long same = __ballot(alive && tile == t_lead);
             uint32_t start = 0;
-            if (lane == 0) start = atomicAdd(count_out, total);
-            start = __shfl(start, 0);
-            if (alive) {
-                uint32_t o = start + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if ((int)lane == leader) start = atomicAdd(&tile_counts_out[t_lead], (uint32_t)__popcll(same));
+            start = __shfl(start, leader);
+            if (alive && tile == t_lead) {
+                uint32_t o = t_lead * TILE + start + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
                 store_ray(qout, o, nr);
                 qout.tr[o] = thr.x; qout.tg[o] = thr.y; qout.tb[o] = thr.z;
                 qout.pid[o] = pid;
             }
+            todo &= ~same;
         }
     }
 }
@@ -815,13 +883,11 @@ __global__ void __launch_bounds__(BLOCK) k_quantize(const double* accum, uint64_
 
 // rt_trace plumbing: AoS f64 host layout <-> SoA queues.
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_load_rays(const double* rays9, uint32_t n, DQueue<T> q, T* tmin, T* tmax, uint32_t* counts) {
+__global__ void __launch_bounds__(BLOCK) k_load_rays(const double* rays9, uint32_t n, DQueue<T> q, T* tmin, T* tmax,
+                                                      uint32_t* tile_counts) {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i == 0) {
-        counts[0] = n;
-        counts[1] = 0;
-    }
     if (i >= n) return;
+    if (i % TILE == 0) tile_counts[i / TILE] = min(TILE, n - i);
     const double* s = rays9 + (uint64_t)i * 9;
     Ray<T> r;
     r.o = mk((T)s[0], (T)s[1], (T)s[2]);
@@ -874,33 +940,35 @@ __global__ void __launch_bounds__(BLOCK) k_store_rays(DQueue<T> q, uint32_t n, d
 static inline int blocks_for(uint64_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
 
 template <typename T>
-void Launch<T>::raygen(const DScene<T>& S, const DBatch& B, DQueue<T> q, uint32_t n_paths, uint32_t* counts, hipStream_t st) {
-    hipLaunchKernelGGL(k_raygen<T>, dim3(blocks_for(n_paths ? n_paths : 1)), dim3(BLOCK), 0, st, S, B, q, n_paths, counts);
+void Launch<T>::raygen(const DScene<T>& S, const DBatch& B, DQueue<T> q, uint32_t n_paths, uint32_t* tile_counts,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_raygen<T>, dim3(blocks_for(n_paths ? n_paths : 1)), dim3(BLOCK), 0, st, S, B, q, n_paths, tile_counts);
 }
 template <typename T>
 void Launch<T>::extend(const DScene<T>& S, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
-                       uint32_t depth, const uint32_t* count_in, uint32_t* count_out_to_zero,
-                       unsigned long long* ray_total, int stack, int grid_blocks, hipStream_t st) {
+                       uint32_t depth, const uint32_t* tile_offsets, uint32_t n_tiles, int stack, int grid_blocks,
+                       hipStream_t st) {
     if (stack <= 16)
-        hipLaunchKernelGGL((k_extend<T, 16>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, q, h, tmin, tmax, depth, count_in, count_out_to_zero, ray_total);
+        hipLaunchKernelGGL((k_extend<T, 16>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (stack <= 32)
-        hipLaunchKernelGGL((k_extend<T, 32>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, q, h, tmin, tmax, depth, count_in, count_out_to_zero, ray_total);
+        hipLaunchKernelGGL((k_extend<T, 32>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else
-        hipLaunchKernelGGL((k_extend<T, 64>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, q, h, tmin, tmax, depth, count_in, count_out_to_zero, ray_total);
+        hipLaunchKernelGGL((k_extend<T, 64>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
 }
 template <typename T>
 void Launch<T>::shade(const DScene<T>& S, const DBatch& B, DQueue<T> qin, DHits<T> h, DQueue<T> qout, T* sample_rgb,
-                      uint32_t depth, uint32_t max_bounces, const uint32_t* count_in, uint32_t* count_out,
-                      int grid_blocks, hipStream_t st) {
-    hipLaunchKernelGGL(k_shade<T>, dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, qin, h, qout, sample_rgb, depth, max_bounces, count_in, count_out);
+                      uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets, uint32_t* tile_counts_out,
+                      uint32_t n_tiles, int grid_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_shade<T>, dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, qin, h, qout, sample_rgb, depth, max_bounces, tile_offsets, tile_counts_out, n_tiles);
 }
 template <typename T>
 void Launch<T>::accumulate(const T* sample_rgb, uint32_t npix, uint32_t n_samples, double* accum, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate<T>, dim3(blocks_for((uint64_t)npix * 3)), dim3(BLOCK), 0, st, sample_rgb, npix, n_samples, accum);
 }
 template <typename T>
-void Launch<T>::load_rays(const double* rays9, uint32_t n, DQueue<T> q, T* tmin, T* tmax, uint32_t* counts, hipStream_t st) {
-    hipLaunchKernelGGL(k_load_rays<T>, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, rays9, n, q, tmin, tmax, counts);
+void Launch<T>::load_rays(const double* rays9, uint32_t n, DQueue<T> q, T* tmin, T* tmax, uint32_t* tile_counts,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(k_load_rays<T>, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, rays9, n, q, tmin, tmax, tile_counts);
 }
 template <typename T>
 void Launch<T>::store_hits(DQueue<T> q, DHits<T> h, uint32_t n, void* out, hipStream_t st) {
@@ -909,6 +977,10 @@ void Launch<T>::store_hits(DQueue<T> q, DHits<T> h, uint32_t n, void* out, hipSt
 template <typename T>
 void Launch<T>::store_rays(DQueue<T> q, uint32_t n, double* rays9, hipStream_t st) {
     hipLaunchKernelGGL(k_store_rays<T>, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, q, n, rays9);
+}
+void launch_scan_tiles(const uint32_t* tile_counts, uint32_t n_tiles, uint32_t* tile_offsets, uint32_t* counts_to_zero,
+                       uint32_t* total_out, unsigned long long* ray_total, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, st, tile_counts, n_tiles, tile_offsets, counts_to_zero, total_out, ray_total);
 }
 void launch_quantize(const double* accum, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb8, hipStream_t st) {
     uint64_t n = n_pixels * 3;

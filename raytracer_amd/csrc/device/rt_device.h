@@ -120,6 +120,7 @@ struct DHits {
     int32_t *owner, *sub, *world_index;     // only written when non-null (rt_trace)
 };
 static constexpr uint32_t RT_MISS = 0x7fffffffu;
+#define RT_TILE 4096u  // queue slots per tile (kernels.hip: TILE)
 
 struct DBatch {      // which pixels / samples the paths of a batch stand for
     uint32_t width, height, j0, npix;  // npix = width * rows in the band
@@ -131,21 +132,25 @@ struct DBatch {      // which pixels / samples the paths of a batch stand for
 // Launch wrappers (kernels.hip).  `stack` selects the LDS traversal-stack depth (16/32/64).
 template <typename T>
 struct Launch {
-    static void raygen(const DScene<T>& S, const DBatch& B, DQueue<T> q, uint32_t n_paths, uint32_t* counts,
+    static void raygen(const DScene<T>& S, const DBatch& B, DQueue<T> q, uint32_t n_paths, uint32_t* tile_counts,
                        hipStream_t st);
     static void extend(const DScene<T>& S, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
-                       uint32_t depth, const uint32_t* count_in, uint32_t* count_out_to_zero,
-                       unsigned long long* ray_total, int stack, int grid_blocks, hipStream_t st);
+                       uint32_t depth, const uint32_t* tile_offsets, uint32_t n_tiles, int stack, int grid_blocks,
+                       hipStream_t st);
     static void shade(const DScene<T>& S, const DBatch& B, DQueue<T> qin, DHits<T> h, DQueue<T> qout, T* sample_rgb,
-                      uint32_t depth, uint32_t max_bounces, const uint32_t* count_in, uint32_t* count_out,
-                      int grid_blocks, hipStream_t st);
+                      uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets, uint32_t* tile_counts_out,
+                      uint32_t n_tiles, int grid_blocks, hipStream_t st);
     static void accumulate(const T* sample_rgb, uint32_t npix, uint32_t n_samples, double* accum, hipStream_t st);
-    static void load_rays(const double* rays9, uint32_t n, DQueue<T> q, T* tmin, T* tmax, uint32_t* counts,
+    static void load_rays(const double* rays9, uint32_t n, DQueue<T> q, T* tmin, T* tmax, uint32_t* tile_counts,
                           hipStream_t st);
     static void store_hits(DQueue<T> q, DHits<T> h, uint32_t n, void* out_rt_hit, hipStream_t st);
     static void store_rays(DQueue<T> q, uint32_t n, double* rays9, hipStream_t st);
 };
 
+// Exclusive scan of per-tile counts -> tile_offsets[0..n_tiles]; zeroes counts_to_zero[0..n_tiles) if
+// non-null; *total_out = total; *ray_total += total if non-null.
+void launch_scan_tiles(const uint32_t* tile_counts, uint32_t n_tiles, uint32_t* tile_offsets, uint32_t* counts_to_zero,
+                       uint32_t* total_out, unsigned long long* ray_total, hipStream_t st);
 void launch_quantize(const double* accum, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb8, hipStream_t st);
 
 }  // namespace rtd
