@@ -3,12 +3,13 @@
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
 ARCH     ?= gfx950
+EXTEND_WAVES ?= 4
 HOSTDIR  := raytracer_amd/csrc/host
 LIBDIR   := raytracer_amd/lib
 OBJDIR   := build/obj
 
 CXXFLAGS  := -O2 -fPIC -std=c++17 -Wall -Wextra -ffp-contract=off
-HIPFLAGS  := -O3 -fPIC -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -Wall -Wno-unused-parameter
+HIPFLAGS  := -O3 -fPIC -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -Wall -Wno-unused-parameter -DRT_EXTEND_WAVES=$(EXTEND_WAVES)
 
 HOST_SRCS := $(HOSTDIR)/json5.cpp $(HOSTDIR)/scene_config.cpp $(HOSTDIR)/obj_loader.cpp \
              $(HOSTDIR)/image_io.cpp $(HOSTDIR)/flatten.cpp

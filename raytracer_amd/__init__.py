@@ -22,7 +22,8 @@ __all__ = [
     "PRECISION_F64", "PRECISION_F32", "LIB_PATH",
 ]
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt_mi355x.so")
+# RT_MI355X_LIB overrides the library path (A/B runs of kernel variants); default: the in-tree build.
+LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt_mi355x.so")
 
 PRECISION_F64 = 0
 PRECISION_F32 = 1

@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<
 }
 
 template <typename T, int STACK>
-__global__ void __launch_bounds__(BLOCK) k_extend(DScene<T> S, DBatch B, DQueue<T> q, DHits<T> h, const T* tmin_arr,
+__global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, DBatch B, DQueue<T> q, DHits<T> h, const T* tmin_arr,
                                                    const T* tmax_arr, uint32_t depth,
                                                    const uint32_t* __restrict__ tile_offsets, uint32_t n_tiles) {
     __shared__ int32_t lds_stack[STACK * BLOCK];
