@@ -223,6 +223,8 @@ struct Engine : EngineBase {
     DevBuf<rtd::DImage> images;
     DevBuf<uint8_t> texels;
     DevBuf<int32_t> top_list;
+    DevBuf<unsigned char> small_blob;
+    rtd::DSmallScene small;
     // work buffers
     DevBuf<T> qslab[2], hslab, sample_rgb, tminmax;
     DevBuf<uint32_t> qpid[2], hmat;
@@ -377,7 +379,35 @@ struct Engine : EngineBase {
         cvt3(S.sky.colour, d.sky.colour); cvt3(S.sky.unit_dir, d.sky.unit_dir);
         cvt3(S.sky.colour0, d.sky.colour0); cvt3(S.sky.colour1, d.sky.colour1);
         stack_depth = d.stack_depth;
+        build_small_scene(d);
         have_scene = true;
+    }
+
+    // Packs the traversal records of a small scene into one blob for LDS staging (k_extend<.., true>).
+    void build_small_scene(const rt_scene_desc& d) {
+        std::memset(&small, 0, sizeof(small));
+        struct Part { const void* dev; size_t bytes; };
+        const Part parts[9] = {
+            {nodes.p, d.n_nodes * sizeof(rtd::DNode<T>)},       {objects.p, d.n_objects * sizeof(rtd::DObject)},
+            {xforms.p, d.n_xforms * sizeof(rtd::DXform<T>)},    {spheres.p, d.n_spheres * sizeof(rtd::DSphere<T>)},
+            {moving_spheres.p, d.n_moving_spheres * sizeof(rtd::DMovingSphere<T>)},
+            {rects.p, d.n_rects * sizeof(rtd::DRect<T>)},       {planes.p, d.n_planes * sizeof(rtd::DPlane<T>)},
+            {media.p, d.n_media * sizeof(rtd::DMedium<T>)},     {top_list.p, d.n_top * sizeof(int32_t)}};
+        size_t total = 0;
+        uint32_t off[9];
+        for (int k = 0; k < 9; k++) {
+            off[k] = (uint32_t)total;
+            total += (parts[k].bytes + 15) & ~(size_t)15;
+        }
+        if (total == 0 || total > RT_LDS_SCENE_BYTES || d.stack_depth > 16) return;
+        small_blob.ensure(total);
+        HIP_CHECK(hipMemset(small_blob.p, 0, total));
+        for (int k = 0; k < 9; k++)
+            if (parts[k].bytes)
+                HIP_CHECK(hipMemcpy(small_blob.p + off[k], parts[k].dev, parts[k].bytes, hipMemcpyDeviceToDevice));
+        small.blob = small_blob.p;
+        small.bytes = (uint32_t)total;
+        std::memcpy(small.off, off, sizeof(off));
     }
 
     void ensure_capacity(size_t n, bool with_ids) {
@@ -440,7 +470,7 @@ struct Engine : EngineBase {
             T* tmax = tminmax.p + capacity;
             rtd::Launch<T>::load_rays(io_f64.p, (uint32_t)m, q, tmin, tmax, tile_counts[0].p, stream);
             rtd::launch_scan_tiles(tile_counts[0].p, tiles_for(m), tile_offsets.p, nullptr, counts.p, nullptr, stream);
-            rtd::Launch<T>::extend(S, B, q, h, tmin, tmax, 0, tile_offsets.p, tiles_for(m), stack_depth, grid_for(m), stream);
+            rtd::Launch<T>::extend(S, small, B, q, h, tmin, tmax, 0, tile_offsets.p, tiles_for(m), stack_depth, grid_for(m), stream);
             rtd::Launch<T>::store_hits(q, h, (uint32_t)m, io_hits.p, stream);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipMemcpyAsync(out + base, io_hits.p, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
@@ -511,7 +541,7 @@ struct Engine : EngineBase {
                     spans.push_back({ev, 0});
                     HIP_CHECK(hipEventRecord(event(ev), stream));
                 }
-                rtd::Launch<T>::extend(S, B, queue(in), hits(false), nullptr, nullptr, depth, tile_offsets.p, n_tiles,
+                rtd::Launch<T>::extend(S, small, B, queue(in), hits(false), nullptr, nullptr, depth, tile_offsets.p, n_tiles,
                                        stack_depth, grid, stream);
                 if (timing) {
                     HIP_CHECK(hipEventRecord(event(ev + 1), stream));

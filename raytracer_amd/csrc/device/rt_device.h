@@ -104,6 +104,16 @@ struct DScene {
     DSky<T> sky;
 };
 
+// Small scenes: one contiguous copy of nodes | objects | xforms | spheres | moving_spheres | rects |
+// planes | media | top_list (byte offsets in that order, each 16-byte aligned) that every block
+// of k_extend stages into LDS.  blob == nullptr when the scene is too large.
+#define RT_LDS_SCENE_BYTES 16384
+struct DSmallScene {
+    const unsigned char* blob;
+    uint32_t bytes;  // multiple of 16, <= RT_LDS_SCENE_BYTES
+    uint32_t off[9];
+};
+
 // Ray / path queue: one SoA slab of `capacity` entries per field (coalesced per field).
 template <typename T>
 struct DQueue {
@@ -134,7 +144,7 @@ template <typename T>
 struct Launch {
     static void raygen(const DScene<T>& S, const DBatch& B, DQueue<T> q, uint32_t n_paths, uint32_t* tile_counts,
                        hipStream_t st);
-    static void extend(const DScene<T>& S, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
+    static void extend(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
                        uint32_t depth, const uint32_t* tile_offsets, uint32_t n_tiles, int stack, int grid_blocks,
                        hipStream_t st);
     static void shade(const DScene<T>& S, const DBatch& B, DQueue<T> qin, DHits<T> h, DQueue<T> qout, T* sample_rgb,
