@@ -180,11 +180,22 @@ def main() -> None:
         return
 
     ms_extend, n_extend = float(t[2]), float(t[3])
-    bpr = extend_bytes_per_ray(args.scene, args.precision)
-    # rank 0's own extend launches: bytes per launch / mean launch duration
-    bytes_per_launch = bpr * rays / max(n_extend, 1.0)
+    r = REC[args.precision]
+    counts = scene.counts()
+    # Records k_extend can touch (everything but materials / texels), as laid out in HBM.
+    scene_bytes = (counts["nodes"] * r["node"] + counts["objects"] * r["object"] + counts["xforms"] * r["xform"]
+                   + counts["rects"] * r["rect"] + counts["spheres"] * r["sphere"] + counts["triangles"] * r["triangle"]
+                   + counts["planes"] * r["plane"])
+    # Algorithmic (compulsory) HBM bytes of one k_extend launch: every live ray is read once
+    # (origin, direction, time, path id) and its hit record written once; the scene is read once.
+    # The records a traversal touches again and again (SURVEY.md 8d's per-ray sum) are served by
+    # LDS / L2 / Infinity Cache and are reported separately as `touched`.
+    rays_per_launch = rays / max(n_extend, 1.0)
     ms_per_launch = ms_extend / max(n_extend, 1.0)
+    bytes_per_launch = (r["ray"] + r["hit"]) * rays_per_launch + scene_bytes
     achieved_gbs = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+    touched_bpr = extend_bytes_per_ray(args.scene, args.precision)
+    touched_gbs = touched_bpr * rays / (ms_extend * 1e-3) / 1e9 if ms_extend > 0 else 0.0
     flops = extend_flops_per_ray(args.scene) * rays / (ms_extend * 1e-3) / 1e12 if ms_extend > 0 else 0.0
     valu_peak = FP64_VALU_PEAK_TFLOPS if args.precision == "f64" else FP32_VALU_PEAK_TFLOPS
     out = {
@@ -209,8 +220,11 @@ def main() -> None:
         "roofline": {
             "bound": "hbm", "kernel": "k_extend", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-            "bytes_per_ray": bpr, "launches": n_extend, "avg_launch_ms": ms_per_launch,
-            "note": "scene fits in L2 / Infinity Cache; the VALU side is in roofline_valu",
+            "bytes_per_launch": bytes_per_launch, "bytes_per_ray": r["ray"] + r["hit"], "scene_bytes": scene_bytes,
+            "launches": n_extend, "avg_launch_ms": ms_per_launch, "rays_per_launch": rays_per_launch,
+            "touched": {"bytes_per_ray": touched_bpr, "achieved_GBps": touched_gbs,
+                        "note": "all records the reference traversal touches per ray (SURVEY 8d sum, f64 sizes); served mostly by LDS / L2 / Infinity Cache"},
+            "note": "k_extend is bound by dependent-fetch latency and f64 VALU, not by HBM bandwidth (see roofline_valu and DESIGN.md)",
         },
         "roofline_valu": {"kernel": "k_extend", "achieved": flops, "peak": valu_peak, "unit": "TFLOP/s", "frac": flops / valu_peak},
         "stage_ms_per_step": {"extend": ms_extend / args.steps, "shade": float(t[4]) / args.steps, "gpu_total": float(t[5]) / args.steps},

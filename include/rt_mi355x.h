@@ -38,8 +38,10 @@ typedef enum rt_status {
  */
 
 /* BVH node (BVHNode + its leaf Vec, src/hitting.rs:141-229).  Interior: left/right are
- * node indices and lo/hi the box.  Leaf: left = -1 - payload, right = RT_LEAF_*; the box is
- * unused (the reference never box-tests a leaf list). */
+ * node indices and lo/hi the box the reference tests (AABB::intersects).  Leaf: left =
+ * -1 - payload, right = RT_LEAF_*; lo/hi = bounding_box() of the leaf's object / triangle.  The
+ * reference never box-tests a leaf list; the library may use that box, padded, to skip the
+ * leaf's primitive test when the ray cannot reach it (conservative: results do not change). */
 typedef struct rt_node {
     double lo[3], hi[3];
     int32_t left, right;

@@ -210,7 +210,9 @@ struct Engine : EngineBase {
     bool have_scene = false;
     int stack_depth = 16;
     rtd::DScene<T> S;
-    DevBuf<rtd::DNode<T>> nodes;
+    DevBuf<rtd::DNode2> nodes2;
+    size_t n_nodes2 = 0;
+    DevBuf<rtd::DNode<T>> nodes_own;  // only kept when the scene is small enough for LDS staging
     DevBuf<rtd::DObject> objects;
     DevBuf<rtd::DXform<T>> xforms;
     DevBuf<rtd::DSphere<T>> spheres;
@@ -251,30 +253,25 @@ struct Engine : EngineBase {
     void upload(const rt_scene_desc& d) override {
         validate(d);
         have_scene = false;
+        // Traversal layout: the reference-style tree (rt_node: every node holds its own f64 box) is
+        // re-laid as DNode2 records that hold the boxes of both children (see rt_device.h).
+        std::vector<int32_t> root2(d.n_nodes, -1);  // rt_node root index -> DNode2 super-root index
         {
-            std::vector<rtd::DNode<T>> v(d.n_nodes);
-            for (size_t i = 0; i < v.size(); i++) {
-                cvt3(v[i].lo, d.nodes[i].lo);
-                cvt3(v[i].hi, d.nodes[i].hi);
-                if (sizeof(T) == 4 && d.nodes[i].left >= 0) {
-                    // f32 boxes are rounded outwards so that narrowing can never cull a hit the f64
-                    // box admits.  (Side effect, fast mode only: a zero-thickness box no longer
-                    // culls itself as it does in the reference)
-                    for (int k = 0; k < 3; k++) {
-                        if ((double)v[i].lo[k] > d.nodes[i].lo[k]) v[i].lo[k] = (T)std::nextafterf((float)v[i].lo[k], -INFINITY);
-                        if ((double)v[i].hi[k] < d.nodes[i].hi[k]) v[i].hi[k] = (T)std::nextafterf((float)v[i].hi[k], INFINITY);
-                    }
-                }
-                v[i].left = d.nodes[i].left;
-                v[i].right = d.nodes[i].right;
-            }
-            nodes.upload(v);
+            std::vector<rtd::DNode2> v;
+            v.reserve(d.n_nodes / 2 + 8);
+            const float pad = box_pad(d);
+            if (d.tlas_root >= 0) root2[d.tlas_root] = build_nodes2(d, d.tlas_root, pad, v);
+            for (uint64_t i = 0; i < d.n_objects; i++)
+                if (d.objects[i].kind == RT_OBJ_BLAS && root2[d.objects[i].first] < 0)
+                    root2[d.objects[i].first] = build_nodes2(d, d.objects[i].first, pad, v);
+            nodes2.upload(v);
+            n_nodes2 = v.size();
         }
         {
             std::vector<rtd::DObject> v(d.n_objects);
             for (size_t i = 0; i < v.size(); i++) {
                 const rt_object& o = d.objects[i];
-                v[i] = rtd::DObject{o.kind, o.xform, o.first, o.count, o.world_index, {0, 0, 0}};
+                v[i] = rtd::DObject{o.kind, o.xform, o.kind == RT_OBJ_BLAS ? root2[o.first] : o.first, o.count, o.world_index, {0, 0, 0}};
             }
             objects.upload(v);
         }
@@ -364,12 +361,14 @@ struct Engine : EngineBase {
         }
         texels.upload(std::vector<uint8_t>(d.texels, d.texels + d.n_texel_bytes));
         top_list.upload(std::vector<int32_t>(d.top_list, d.top_list + d.n_top));
-        S.nodes = nodes.p; S.objects = objects.p; S.xforms = xforms.p; S.spheres = spheres.p;
+        S.nodes2 = nodes2.p; S.objects = objects.p; S.xforms = xforms.p; S.spheres = spheres.p;
         S.moving_spheres = moving_spheres.p; S.rects = rects.p; S.triangles = triangles.p; S.planes = planes.p;
         S.media = media.p; S.materials = materials.p; S.images = images.p; S.texels = texels.p;
         S.top_list = top_list.p;
         S.n_top = (int32_t)d.n_top;
-        S.tlas_root = d.tlas_root;
+        S.tlas_root = d.tlas_root >= 0 ? root2[d.tlas_root] : -1;
+        S.tlas_root_own = d.tlas_root;
+        S.nodes = nullptr;
         const rt_camera& c = d.camera;
         cvt3(S.camera.origin, c.origin); cvt3(S.camera.lower_left_corner, c.lower_left_corner);
         cvt3(S.camera.horizontal, c.horizontal); cvt3(S.camera.vertical, c.vertical);
@@ -383,12 +382,97 @@ struct Engine : EngineBase {
         have_scene = true;
     }
 
+    // Padding of the f32 traversal boxes.  The f32 slab test computes (plane - origin) * (1/d) with a
+    // relative error of a few 2^-24; a pad of 8e-6 x (largest coordinate magnitude in the scene,
+    // camera and transform offsets included) exceeds that error by more than an order of magnitude
+    // for every ray that starts inside the scene's extent, so the test never rejects a box the exact
+    // f64 test of the reference accepts.
+    static float box_pad(const rt_scene_desc& d) {
+        double scale = 1e-30;
+        auto take = [&](double x) {
+            if (std::isfinite(x)) scale = std::max(scale, std::fabs(x));
+        };
+        for (uint64_t i = 0; i < d.n_nodes; i++)
+            for (int k = 0; k < 3; k++) {
+                take(d.nodes[i].lo[k]);
+                take(d.nodes[i].hi[k]);
+            }
+        for (uint64_t i = 0; i < d.n_xforms; i++)
+            for (int k = 0; k < 3; k++) take(d.xforms[i].b[k]);
+        for (int k = 0; k < 3; k++) take(d.camera.origin[k]);
+        return (float)(8e-6 * scale);
+    }
+
+    // One child slot of a DNode2 from reference node `idx`; returns the child reference.
+    static int32_t node2_child(const rt_scene_desc& d, int32_t idx, float pad, std::vector<rtd::DNode2>& out, float* lo,
+                               float* hi) {
+        const rt_node& nd = d.nodes[idx];
+        bool well_formed = true, flat = false;
+        for (int k = 0; k < 3; k++) {
+            if (!(nd.lo[k] <= nd.hi[k]) || !std::isfinite(nd.lo[k]) || !std::isfinite(nd.hi[k])) well_formed = false;
+            if (nd.lo[k] == nd.hi[k]) flat = true;
+        }
+        for (int k = 0; k < 3; k++) {
+            if (well_formed) {
+                lo[k] = std::nextafterf((float)nd.lo[k] - pad, -INFINITY);
+                hi[k] = std::nextafterf((float)nd.hi[k] + pad, INFINITY);
+                if ((double)lo[k] > nd.lo[k]) lo[k] = std::nextafterf(lo[k], -INFINITY);
+                if ((double)hi[k] < nd.hi[k]) hi[k] = std::nextafterf(hi[k], INFINITY);
+            } else {  // malformed bounds (e.g. a Block given with swapped corners): never cull
+                lo[k] = -INFINITY;
+                hi[k] = INFINITY;
+            }
+        }
+        if (nd.left < 0) return nd.left;  // leaf: payload reference, box = its (padded) bounds
+        // Interior node.  AABB::intersects rejects when max_dist <= min_dist (src/hitting.rs:262): a box
+        // of zero thickness on an axis yields t0 == t1 there and is culled for every ray, so the whole
+        // subtree is invisible in the reference - dropped here for the same result.
+        if (well_formed && flat) return rtd::RT_EMPTY;
+        int32_t me = (int32_t)out.size();
+        out.emplace_back();
+        rtd::DNode2 n;
+        std::memset(&n, 0, sizeof(n));
+        n.child[0] = node2_child(d, nd.left, pad, out, n.lo[0], n.hi[0]);
+        n.child[1] = node2_child(d, nd.right, pad, out, n.lo[1], n.hi[1]);
+        out[(size_t)me] = n;
+        return me;
+    }
+
+    // DNode2 super-root for the reference BVH rooted at `root`: child 0 = that root, child 1 empty.
+    static int32_t build_nodes2(const rt_scene_desc& d, int32_t root, float pad, std::vector<rtd::DNode2>& out) {
+        int32_t me = (int32_t)out.size();
+        out.emplace_back();
+        rtd::DNode2 n;
+        std::memset(&n, 0, sizeof(n));
+        n.child[0] = node2_child(d, root, pad, out, n.lo[0], n.hi[0]);
+        n.child[1] = rtd::RT_EMPTY;
+        out[(size_t)me] = n;
+        return me;
+    }
+
     // Packs the traversal records of a small scene into one blob for LDS staging (k_extend<.., true>).
     void build_small_scene(const rt_scene_desc& d) {
         std::memset(&small, 0, sizeof(small));
+        if (d.n_nodes * sizeof(rtd::DNode<T>) > RT_LDS_SCENE_BYTES) return;
+        {
+            std::vector<rtd::DNode<T>> v(d.n_nodes);
+            for (size_t i = 0; i < v.size(); i++) {
+                cvt3(v[i].lo, d.nodes[i].lo);
+                cvt3(v[i].hi, d.nodes[i].hi);
+                if (sizeof(T) == 4) {  // f32 mode: round boxes outwards so that narrowing never culls a hit
+                    for (int k = 0; k < 3; k++) {
+                        if ((double)v[i].lo[k] > d.nodes[i].lo[k]) v[i].lo[k] = (T)std::nextafterf((float)v[i].lo[k], -INFINITY);
+                        if ((double)v[i].hi[k] < d.nodes[i].hi[k]) v[i].hi[k] = (T)std::nextafterf((float)v[i].hi[k], INFINITY);
+                    }
+                }
+                v[i].left = d.nodes[i].left;
+                v[i].right = d.nodes[i].right;
+            }
+            nodes_own.upload(v);
+        }
         struct Part { const void* dev; size_t bytes; };
         const Part parts[9] = {
-            {nodes.p, d.n_nodes * sizeof(rtd::DNode<T>)},       {objects.p, d.n_objects * sizeof(rtd::DObject)},
+            {nodes_own.p, d.n_nodes * sizeof(rtd::DNode<T>)},      {objects.p, d.n_objects * sizeof(rtd::DObject)},
             {xforms.p, d.n_xforms * sizeof(rtd::DXform<T>)},    {spheres.p, d.n_spheres * sizeof(rtd::DSphere<T>)},
             {moving_spheres.p, d.n_moving_spheres * sizeof(rtd::DMovingSphere<T>)},
             {rects.p, d.n_rects * sizeof(rtd::DRect<T>)},       {planes.p, d.n_planes * sizeof(rtd::DPlane<T>)},

@@ -277,6 +277,55 @@ __device__ __forceinline__ bool box_hit(const DNode<T>& n, V3<T> o, V3<T> inv_d,
     return true;
 }
 
+// Conservative f32 slab test against a padded, outward-rounded child box (DNode2).
+// The reference's AABB::intersects (src/hitting.rs:249-268) works in f64 on the exact box and
+// rejects when max <= min; this test may only err towards "hit": the boxes are padded by far
+// more than the f32 rounding of the test (capi.cpp, build_nodes2), tmin is rounded down and the
+// bound up, NaN (0 * inf) is ignored by fminf / fmaxf, and equality counts as a hit.  A node
+// that is visited although the reference would have culled it costs time only: its primitives
+// are tested exactly (f64) against the current bound.  Boxes the reference *always* culls
+// (zero thickness) are removed when the layout is built (RT_EMPTY).
+struct RayF {
+    float ox, oy, oz, ix, iy, iz;
+};
+template <typename T>
+__device__ __forceinline__ RayF ray_f32(const Ray<T>& r) {
+    RayF f;
+    f.ox = (float)r.o.x; f.oy = (float)r.o.y; f.oz = (float)r.o.z;
+    f.ix = 1.0f / (float)r.d.x; f.iy = 1.0f / (float)r.d.y; f.iz = 1.0f / (float)r.d.z;
+    return f;
+}
+__device__ __forceinline__ float round_down(double x) { return __double2float_rd(x); }
+__device__ __forceinline__ float round_up(double x) { return __double2float_ru(x); }
+__device__ __forceinline__ float round_down(float x) { return x; }
+__device__ __forceinline__ float round_up(float x) { return x; }
+
+__device__ __forceinline__ bool box2_hit(const float* lo, const float* hi, const RayF& f, float tmin, float tmax) {
+    float ta = (lo[0] - f.ox) * f.ix, tb = (hi[0] - f.ox) * f.ix;
+    tmin = fmaxf(fminf(ta, tb), tmin);
+    tmax = fminf(fmaxf(ta, tb), tmax);
+    ta = (lo[1] - f.oy) * f.iy; tb = (hi[1] - f.oy) * f.iy;
+    tmin = fmaxf(fminf(ta, tb), tmin);
+    tmax = fminf(fmaxf(ta, tb), tmax);
+    ta = (lo[2] - f.oz) * f.iz; tb = (hi[2] - f.oz) * f.iz;
+    tmin = fmaxf(fminf(ta, tb), tmin);
+    tmax = fminf(fmaxf(ta, tb), tmax);
+    return tmax >= tmin;
+}
+
+struct alignas(16) Node2Regs {  // a DNode2 fetched as four 16-byte loads
+    uint4 q[4];
+    __device__ __forceinline__ const float* lo(int c) const { return (const float*)q + 3 * c; }
+    __device__ __forceinline__ const float* hi(int c) const { return (const float*)q + 6 + 3 * c; }
+    __device__ __forceinline__ int32_t child(int c) const { return ((const int32_t*)q)[12 + c]; }
+};
+__device__ __forceinline__ Node2Regs load_node2(const DNode2* nodes, int idx) {
+    const uint4* p = (const uint4*)(nodes + idx);
+    Node2Regs n;
+    n.q[0] = p[0]; n.q[1] = p[1]; n.q[2] = p[2]; n.q[3] = p[3];
+    return n;
+}
+
 // Per-lane traversal stack in LDS: entry e of lane l lives at stack[e * BLOCK + l], so the
 // 64 lanes of a wave touch 64 consecutive dwords (no bank conflicts).
 struct Stack {
@@ -289,32 +338,50 @@ struct Stack {
 // BVHNode::hit over a triangle BVH (src/hitting.rs:211-229).  The recursion "left with
 // [min,max], then right with [min, min(left.t, max)], right wins if it hits" is a
 // depth-first walk, left child first, with a shrinking upper bound that accepts t <= bound
-// (so the later leaf wins an exact tie, as in the reference).
+// (so the later leaf wins an exact tie, as in the reference).  `root` is a DNode2 whose child 0
+// is the reference's root.
 template <typename T>
 __device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, Stack st, int sp0,
                          T* t_out, int* prim_out) {
-    V3<T> inv_d = mk((T)1.0 / r.d.x, (T)1.0 / r.d.y, (T)1.0 / r.d.z);
+    const RayF f = ray_f32(r);
+    const float tmin32 = round_down(min_dist);
+    float bound32 = round_up(max_dist);
     int sp = sp0;
-    int cur = root;
+    int32_t next = root;
     bool found = false;
     for (;;) {
-        const DNode<T>& n = S.nodes[cur];
-        int left = n.left;
-        if (left < 0) {
-            int tri = -1 - left;
+        // One 64-byte fetch decides a level (both children's boxes); leaves that come up - as the
+        // chosen child or from the stack - are tested exactly before the next node is fetched.
+        const Node2Regs n = load_node2(S.nodes2, next);
+        const int32_t c0 = n.child(0), c1 = n.child(1);
+        const bool h0 = c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32);
+        const bool h1 = c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32);
+        next = RT_EMPTY;
+        if (h0) {
+            next = c0;
+            if (h1) st.put(sp++, c1);
+        } else if (h1) {
+            next = c1;
+        }
+        for (;;) {
+            if (next == RT_EMPTY) {
+                if (sp == sp0) {
+                    *t_out = max_dist;
+                    return found;
+                }
+                next = st.get(--sp);
+            }
+            if (next >= 0) break;
+            const int tri = -1 - next;  // leaf: the exact test, against the current bound
             T t;
             if (triangle_hit(S.triangles[tri], r, min_dist, max_dist, &t)) {
                 max_dist = t;
+                bound32 = round_up(t);
                 *prim_out = tri;
                 found = true;
             }
-        } else if (box_hit(n, r.o, inv_d, min_dist, max_dist)) {
-            st.put(sp++, n.right);
-            cur = left;
-            continue;
+            next = RT_EMPTY;
         }
-        if (sp == sp0) break;
-        cur = st.get(--sp);
     }
     *t_out = max_dist;
     return found;
@@ -390,7 +457,7 @@ __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, 
 
 // world.hit(ray, min, max): the top-level Vec (src/hitting.rs:188-194 -> :88-104) over the
 // world BVH and the unbounded objects; inside the BVH, BVHNode::hit (:211-229).
-template <typename T>
+template <typename T, bool OWN_BOX>
 __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T max_dist, Stack st, uint64_t seed,
                             uint32_t pixel, uint32_t sample, uint32_t depth, T* t_out, Winner* w_out) {
     bool have = false;
@@ -404,11 +471,13 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
         if (entry != RT_TOP_BVH) {
             found = object_hit(S, entry, ray, min_dist, max_dist, st, 0, seed, pixel, sample, depth, &t, &w.prim);
             w.obj = entry;
-        } else {
+        } else if (OWN_BOX) {
+            // Small worlds (staged in LDS): reference-shaped nodes, each with its own f64 box.  Nearly
+            // every ray of a closed box visits nearly every node, so the lanes of a wave stay in step.
             V3<T> inv_d = mk((T)1.0 / ray.d.x, (T)1.0 / ray.d.y, (T)1.0 / ray.d.z);
             T bound = max_dist;
             int sp = 0;
-            int cur = S.tlas_root;
+            int cur = S.tlas_root_own;
             for (;;) {
                 const DNode<T>& n = S.nodes[cur];
                 int left = n.left;
@@ -429,6 +498,45 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                 }
                 if (sp == 0) break;
                 cur = st.get(--sp);
+            }
+            t = bound;
+        } else {
+            const RayF f = ray_f32(ray);
+            const float tmin32 = round_down(min_dist);
+            T bound = max_dist;
+            float bound32 = round_up(bound);
+            int sp = 0;
+            int32_t next = S.tlas_root;
+            for (;;) {  // one step per iteration: one leaf (exact object test) or one node (two box tests)
+                if (next == RT_EMPTY) {
+                    if (sp == 0) break;
+                    next = st.get(--sp);
+                }
+                if (next < 0) {
+                    const int oi = -1 - next;
+                    T th;
+                    int prim;
+                    if (object_hit(S, oi, ray, min_dist, bound, st, sp, seed, pixel, sample, depth, &th, &prim)) {
+                        bound = th;
+                        bound32 = round_up(th);
+                        w.obj = oi;
+                        w.prim = prim;
+                        found = true;
+                    }
+                    next = RT_EMPTY;
+                } else {
+                    const Node2Regs n = load_node2(S.nodes2, next);
+                    const int32_t c0 = n.child(0), c1 = n.child(1);
+                    const bool h0 = c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32);
+                    const bool h1 = c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32);
+                    next = RT_EMPTY;
+                    if (h0) {
+                        next = c0;
+                        if (h1) st.put(sp++, c1);
+                    } else if (h1) {
+                        next = c1;
+                    }
+                }
             }
             t = bound;
         }
@@ -695,7 +803,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
         T max_dist = tmax_arr ? tmax_arr[i] : Lim<T>::inf();
         T t;
         Winner w;
-        if (closest_hit(S, r, min_dist, max_dist, st, B.seed, pixel, sample, depth, &t, &w)) {
+        if (closest_hit<T, LDS_SCENE>(S, r, min_dist, max_dist, st, B.seed, pixel, sample, depth, &t, &w)) {
             Surface<T> sf = make_surface(S, r, t, w);
             h.t[i] = t;
             h.nx[i] = sf.normal.x; h.ny[i] = sf.normal.y; h.nz[i] = sf.normal.z;

@@ -9,10 +9,21 @@
 namespace rtd {
 
 template <typename T>
-struct alignas(16) DNode {  // f64: 64 B, f32: 32 B - one or two 16 B-aligned vector loads
+struct alignas(16) DNode {  // reference-shaped node with its own box (f64: 64 B); small worlds only
     T lo[3], hi[3];
     int32_t left, right;  // interior: children; leaf: left = -1 - payload, right = RT_LEAF_*
 };
+
+// Traversal node: the (padded, outward-rounded f32) boxes of BOTH children live in the parent, so
+// one 64-byte fetch decides a whole level.  child >= 0: interior DNode2 index; child < 0: leaf
+// payload -1 - child (triangle index in a mesh BVH, object index in the world BVH); RT_EMPTY: no
+// child / a child the reference always culls (zero-thickness box).
+struct alignas(16) DNode2 {
+    float lo[2][3], hi[2][3];
+    int32_t child[2];
+    int32_t pad[2];
+};
+static constexpr int32_t RT_EMPTY = (int32_t)0x80000000;
 
 template <typename T>
 struct alignas(16) DXform {  // world -> object: p' = m p + b
@@ -86,7 +97,8 @@ struct DSky {
 
 template <typename T>
 struct DScene {
-    const DNode<T>* nodes;
+    const DNode<T>* nodes;  // own-box nodes of the world BVH; valid only inside k_extend<.., LDS_SCENE = true>
+    const DNode2* nodes2;
     const DObject* objects;
     const DXform<T>* xforms;
     const DSphere<T>* spheres;
@@ -99,12 +111,12 @@ struct DScene {
     const DImage* images;
     const uint8_t* texels;
     const int32_t* top_list;
-    int32_t n_top, tlas_root;
+    int32_t n_top, tlas_root /* DNode2 super-root */, tlas_root_own /* DNode index */, pad_;
     DCamera<T> camera;
     DSky<T> sky;
 };
 
-// Small scenes: one contiguous copy of nodes | objects | xforms | spheres | moving_spheres | rects |
+// Small scenes: one contiguous copy of nodes (own-box form) | objects | xforms | spheres | moving_spheres | rects |
 // planes | media | top_list (byte offsets in that order, each 16-byte aligned) that every block
 // of k_extend stages into LDS.  blob == nullptr when the scene is too large.
 #define RT_LDS_SCENE_BYTES 16384

@@ -340,6 +340,8 @@ private:
         if (hi - lo == 1) {
             rt_node n;
             std::memset(&n, 0, sizeof(n));
+            store(n.lo, items[lo].node_box.lo);  // the leaf's own bounds (never tested by the reference)
+            store(n.hi, items[lo].node_box.hi);
             n.left = -1 - items[lo].payload;
             n.right = leaf_kind;
             out_.nodes[(size_t)idx] = n;
