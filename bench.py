@@ -59,6 +59,20 @@ def extend_flops_per_ray(scene_name: str) -> float:
     return st["nodes_per_ray"] * 21 + st["prims_per_ray"] * PRIM_FLOPS[PRIM_KIND.get(scene_name, "rect")] + st["xforms_per_ray"] * 40
 
 
+def measured_traffic(scene_name: str, prec: str):
+    """HBM bytes per k_extend launch from the PMC passes committed under profiles/ (separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950); None when no pass exists for this scene."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        with open(path) as f:
+            t = json.load(f).get(scene_name)
+        if t and t.get("precision") == prec:
+            return t["traffic_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(scene_path: str, width: int, bounces: int, seed: int) -> dict:
     """CPU oracle on a bounded sample of the workload: same scene / width / bounces, fewer
     samples per pixel (rays per sample are the same in expectation)."""
@@ -219,7 +233,7 @@ def main() -> None:
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_extend", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(args.scene, args.precision),
             "bytes_per_launch": bytes_per_launch, "bytes_per_ray": r["ray"] + r["hit"], "scene_bytes": scene_bytes,
             "launches": n_extend, "avg_launch_ms": ms_per_launch, "rays_per_launch": rays_per_launch,
             "touched": {"bytes_per_ray": touched_bpr, "achieved_GBps": touched_gbs,
