@@ -12,11 +12,12 @@ CXXFLAGS  := -O2 -fPIC -std=c++17 -Wall -Wextra -ffp-contract=off
 HIPFLAGS  := -O3 -fPIC -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -Wall -Wno-unused-parameter -DRT_EXTEND_WAVES=$(EXTEND_WAVES)
 
 HOST_SRCS := $(HOSTDIR)/json5.cpp $(HOSTDIR)/scene_config.cpp $(HOSTDIR)/obj_loader.cpp \
-             $(HOSTDIR)/image_io.cpp $(HOSTDIR)/flatten.cpp
+             $(HOSTDIR)/image_io.cpp $(HOSTDIR)/flatten.cpp $(HOSTDIR)/part_file.cpp \
+             $(HOSTDIR)/progress.cpp $(HOSTDIR)/image_out.cpp $(HOSTDIR)/host_capi.cpp
 HOST_OBJS := $(patsubst $(HOSTDIR)/%.cpp,$(OBJDIR)/%.o,$(HOST_SRCS))
 HOST_HDRS := $(wildcard $(HOSTDIR)/*.hpp) include/rt_mi355x.h
 
-all: $(LIBDIR)/librt_mi355x.so oracle
+all: $(LIBDIR)/librt_mi355x.so bin/raytracer oracle
 
 $(OBJDIR)/%.o: $(HOSTDIR)/%.cpp $(HOST_HDRS)
 	@mkdir -p $(OBJDIR)
@@ -32,13 +33,19 @@ $(OBJDIR)/capi.o: raytracer_amd/csrc/capi.cpp raytracer_amd/csrc/device/rt_devic
 
 $(LIBDIR)/librt_mi355x.so: $(HOST_OBJS) $(OBJDIR)/kernels.o $(OBJDIR)/capi.o
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lz
+
+# Command-line host: the reference's `raytracer` binary over the C ABI.
+bin/raytracer: $(HOSTDIR)/cli_main.cpp $(OBJDIR)/part_file.o $(OBJDIR)/progress.o $(OBJDIR)/image_out.o $(LIBDIR)/librt_mi355x.so
+	@mkdir -p bin
+	$(CXX) $(CXXFLAGS) -Iinclude -o $@ $(HOSTDIR)/cli_main.cpp $(OBJDIR)/part_file.o $(OBJDIR)/progress.o $(OBJDIR)/image_out.o \
+	    -L$(LIBDIR) -lrt_mi355x -lz -lpthread -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -rf build $(LIBDIR)/*.so
+	rm -rf build bin $(LIBDIR)/*.so
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

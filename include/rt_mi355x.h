@@ -243,6 +243,40 @@ int rt_render_rows(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0
                    uint32_t spp, uint32_t max_bounces, uint64_t seed, uint8_t* rgb8, double* sum_rgb,
                    rt_stats* stats /* may be NULL */);
 
+/* ------------------------------------------------------------------ host I/O (no GPU)
+ * The file formats either side of the row loop, for hosts that keep the reference's
+ * command-line behaviour (bin/raytracer does).  Errors: rt_last_global_error(). */
+
+/* PartFile::new (src/part_file.rs:13-30) + the "<W> <H>\n" header monitor_progress writes
+ * (src/main.rs:197-200): creates "<basename(image_name)>.<n>.PART" in the working directory
+ * with the first free n. */
+typedef struct rt_part_file rt_part_file;
+int rt_part_file_create(const char* image_name, uint32_t width, uint32_t height, rt_part_file** out);
+const char* rt_part_file_path(const rt_part_file* part);
+/* PartFile::write_part (src/part_file.rs:32-39): "L<j> " + row + "\n", flushed.  line_number is
+ * the bottom-up row index j of src/main.rs:121. */
+int rt_part_file_write(rt_part_file* part, uint32_t line_number, const uint8_t* row, size_t row_bytes);
+/* Closes the file and frees the handle; remove != 0 deletes it (src/main.rs:239-241). */
+int rt_part_file_finish(rt_part_file* part, int remove);
+/* PartFile::read (src/part_file.rs:41-99).  rows: image_height * image_width * 3 bytes indexed
+ * by j; present[j] = 1 for rows found in the file.  Fails with the reference's messages
+ * (dimension mismatch, "Missing leading L", ...) unless recover_corrupt stops at the first bad
+ * record instead. */
+int rt_part_file_read(const char* name, uint32_t image_height, uint32_t image_width, int recover_corrupt,
+                      uint8_t* rows, uint8_t* present);
+
+/* img.save(output_file) (src/main.rs:161-162): rgb8 is width*height*3 bytes, top row first; the
+ * encoder follows the extension (.png, .ppm/.pnm, .bmp; anything else is RT_ERR_IO). */
+int rt_save_image(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb8);
+
+/* TimedProgressBar (src/progress.rs:12-115) drawing on a duplicate of file descriptor fd. */
+typedef struct rt_progress rt_progress;
+int rt_progress_create(int fd, size_t length, const char* label, const char* glyphs, uint32_t number_samples,
+                       uint32_t times_will_be_updated, rt_progress** out);
+void rt_progress_update(rt_progress* progress);
+void rt_progress_clear(rt_progress* progress);
+void rt_progress_free(rt_progress* progress);
+
 #ifdef __cplusplus
 }
 #endif

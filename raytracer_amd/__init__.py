@@ -19,7 +19,7 @@ import numpy as np
 
 __all__ = [
     "load_library", "Scene", "Renderer", "RtError", "RtStats", "RAY_DTYPE", "HIT_DTYPE",
-    "PRECISION_F64", "PRECISION_F32", "LIB_PATH",
+    "PRECISION_F64", "PRECISION_F32", "LIB_PATH", "PartFile", "read_part_file", "save_image", "ProgressBar",
 ]
 
 # RT_MI355X_LIB overrides the library path (A/B runs of kernel variants); default: the in-tree build.
@@ -76,6 +76,17 @@ EXPORTS = [
     ("rt_render_accum_device", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _vp, C.POINTER(RtStats)]),
     ("rt_quantize_device", C.c_int, [_vp, _vp, _u64, _u32, _vp]),
     ("rt_render_rows", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _vp, _vp, C.POINTER(RtStats)]),
+    # host I/O
+    ("rt_part_file_create", C.c_int, [C.c_char_p, _u32, _u32, C.POINTER(_vp)]),
+    ("rt_part_file_path", C.c_char_p, [_vp]),
+    ("rt_part_file_write", C.c_int, [_vp, _u32, _vp, C.c_size_t]),
+    ("rt_part_file_finish", C.c_int, [_vp, C.c_int]),
+    ("rt_part_file_read", C.c_int, [C.c_char_p, _u32, _u32, C.c_int, _vp, _vp]),
+    ("rt_save_image", C.c_int, [C.c_char_p, _u32, _u32, _vp]),
+    ("rt_progress_create", C.c_int, [C.c_int, C.c_size_t, C.c_char_p, C.c_char_p, _u32, _u32, C.POINTER(_vp)]),
+    ("rt_progress_update", None, [_vp]),
+    ("rt_progress_clear", None, [_vp]),
+    ("rt_progress_free", None, [_vp]),
 ]
 
 _lib = None
@@ -235,3 +246,75 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+def _check_global(rc: int) -> None:
+    if rc != 0:
+        raise RtError(rc, load_library().rt_last_global_error().decode("utf-8", "replace"))
+
+
+class PartFile:
+    """A .PART recovery file being written (PartFile::new / write_part, src/part_file.rs:13-39)."""
+
+    def __init__(self, image_name: str, width: int, height: int):
+        lib = load_library()
+        out = _vp()
+        _check_global(lib.rt_part_file_create(os.fsencode(image_name), width, height, C.byref(out)))
+        self._h = out.value
+        self.path = os.fsdecode(lib.rt_part_file_path(self._h))
+
+    def write(self, line_number: int, row) -> None:
+        row = np.ascontiguousarray(row, dtype=np.uint8)
+        _check_global(load_library().rt_part_file_write(self._h, line_number, row.ctypes.data, row.size))
+
+    def finish(self, remove: bool) -> None:
+        h, self._h = self._h, None
+        if h:
+            _check_global(load_library().rt_part_file_finish(h, int(remove)))
+
+    def __del__(self):
+        try:
+            self.finish(False)
+        except Exception:
+            pass
+
+
+def read_part_file(name: str, height: int, width: int, recover_corrupt: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """PartFile::read (src/part_file.rs:41-99): (rows [height, width, 3] uint8 indexed by j, present [height] bool)."""
+    rows = np.zeros((height, width, 3), dtype=np.uint8)
+    present = np.zeros(height, dtype=np.uint8)
+    _check_global(load_library().rt_part_file_read(os.fsencode(name), height, width, int(recover_corrupt),
+                                                   rows.ctypes.data, present.ctypes.data))
+    return rows, present.astype(bool)
+
+
+def save_image(path: str, rgb8) -> None:
+    """img.save (src/main.rs:161-162): rgb8 [height, width, 3] uint8, top row first."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    if rgb8.ndim != 3 or rgb8.shape[2] != 3:
+        raise ValueError("rgb8 must be [height, width, 3]")
+    _check_global(load_library().rt_save_image(os.fsencode(path), rgb8.shape[1], rgb8.shape[0], rgb8.ctypes.data))
+
+
+class ProgressBar:
+    """TimedProgressBar (src/progress.rs:12-115) on a file descriptor (default stderr)."""
+
+    def __init__(self, length: int, label: str, glyphs: str, number_samples: int, times_will_be_updated: int, fd: int = 2):
+        out = _vp()
+        _check_global(load_library().rt_progress_create(fd, length, label.encode(), glyphs.encode(), number_samples,
+                                                        times_will_be_updated, C.byref(out)))
+        self._h = out.value
+
+    def update(self) -> None:
+        load_library().rt_progress_update(self._h)
+
+    def clear(self) -> None:
+        load_library().rt_progress_clear(self._h)
+
+    def close(self) -> None:
+        h, self._h = self._h, None
+        if h:
+            load_library().rt_progress_free(h)
+
+    def __del__(self):
+        self.close()

@@ -693,6 +693,11 @@ struct rt_context {
     DevBuf<uint8_t> tmp_rgb8;
 };
 
+namespace rt {
+// host_capi.cpp reports its errors through the same thread-local text.
+void set_global_error(const std::string& msg) { g_error = msg; }
+}  // namespace rt
+
 template <typename F>
 static int guard_global(F&& f) {
     try {

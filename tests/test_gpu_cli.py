@@ -1,0 +1,92 @@
+"""bin/raytracer end to end on the GPU: the command line of reference src/main.rs (row loop,
+monitor thread, .PART files, image output) over the C ABI.  The image it writes must be the
+library's own render of the same seed (bit-exact) and the oracle's (>= 99 % of the bytes)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "bin", "raytracer")
+SCENE = os.path.join(ROOT, "examples", "cornell.json5")
+W = H = 48
+SPP, MB = 8, 12
+
+
+def _cli(*args, cwd):
+    return subprocess.run([CLI, *args], capture_output=True, cwd=cwd, timeout=110)
+
+
+def _read_ppm(path):
+    raw = open(path, "rb").read()
+    head = b"P6\n%d %d\n255\n" % (W, H)
+    assert raw.startswith(head)
+    return np.frombuffer(raw[len(head):], dtype=np.uint8).reshape(H, W, 3)
+
+
+def _render(tmp_path, *extra, seed=5, out="out.ppm"):
+    r = _cli(SCENE, out, "-w", str(W), "-s", str(SPP), "-m", str(MB), "--seed", str(seed), *extra, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr.decode()
+    return _read_ppm(os.path.join(tmp_path, out)), r
+
+
+def test_cli_image_is_the_library_render_and_the_oracle_render(tmp_path, gpu_scenes, oracle_scenes):
+    img, r = _render(tmp_path, "--stats", "--progress-bar-len", "60")
+    sc, ren = gpu_scenes("cornell")
+    assert sc.image_height(W) == H
+    rgb8, _, stats = ren.render_rows(W, H, 0, H, SPP, MB, seed=5)
+    assert np.array_equal(img, rgb8[::-1])  # the file has the top row (j = H-1) first
+    o8, _, _ = oracle_scenes("cornell").render(W, H, 0, H, SPP, MB, seed=5, threads=8)
+    assert (img == o8[::-1]).mean() >= 0.99
+    err = r.stderr.decode()
+    assert "Completed in 0:0" in err and "Rendering: [" in err and f"{W * H * SPP} paths" in err
+    assert os.listdir(tmp_path) == ["out.ppm"]  # the part file is removed after a complete render
+
+
+def test_cli_bands_quiet_and_formats(tmp_path):
+    whole, _ = _render(tmp_path)
+    banded, r = _render(tmp_path, "--band-rows", "7", "-q", "--no-part-file", out="banded.ppm")
+    assert np.array_equal(whole, banded)  # counter-based streams: the batching does not change a pixel
+    assert r.stderr == b""
+    f32, _ = _render(tmp_path, "--precision", "f32", out="f32.ppm")
+    assert (np.abs(f32.astype(int) - whole.astype(int)) <= 2).mean() >= 0.97
+    r = _cli(SCENE, "out.png", "-w", str(W), "-s", "2", "-m", "4", "-q", cwd=tmp_path)
+    assert r.returncode == 0 and open(os.path.join(tmp_path, "out.png"), "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    r = _cli(SCENE, "out.jpg", "-w", str(W), "-s", "1", "-m", "2", cwd=tmp_path)
+    assert r.returncode == 1 and b"image format" in r.stderr
+
+
+def test_cli_recovers_rows_from_a_part_file(tmp_path):
+    import raytracer_amd as rt
+
+    a, _ = _render(tmp_path, seed=1, out="a.ppm")
+    b, _ = _render(tmp_path, seed=2, out="b.ppm")
+    assert not np.array_equal(a, b)
+    # a part file holding rows 40..47 and 10..19 of render A (j counts from the bottom of the image)
+    kept = list(range(47, 39, -1)) + list(range(19, 9, -1))
+    old = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        pf = rt.PartFile("c.ppm", W, H)
+        for j in kept:
+            pf.write(j, a[H - 1 - j])
+        pf.finish(remove=False)
+    finally:
+        os.chdir(old)
+    assert pf.path == "c.ppm.0.PART"
+    # truncate the last record: without --recover-corrupt the read fails, with it the row is dropped
+    path = os.path.join(tmp_path, pf.path)
+    raw = open(path, "rb").read()
+    open(path, "wb").write(raw[:-20])
+    r = _cli(SCENE, "c.ppm", "-w", str(W), "-s", str(SPP), "-m", str(MB), "--seed", "2", "-r", pf.path, cwd=tmp_path)
+    assert r.returncode == 1 and b"failed to fill whole buffer" in r.stderr
+    c, _ = _render(tmp_path, "-r", pf.path, "--recover-corrupt", seed=2, out="c.ppm")
+    kept = kept[:-1]
+    for j in range(H):
+        want = a if j in kept else b
+        assert np.array_equal(c[H - 1 - j], want[H - 1 - j]), f"row j={j}"
+    # the recovered file is left alone, the new part file (c.ppm.1.PART) is gone
+    assert sorted(os.listdir(tmp_path)) == ["a.ppm", "b.ppm", "c.ppm", "c.ppm.0.PART"]

@@ -1,0 +1,227 @@
+"""Host-side file formats of the command line (no GPU): .PART recovery files
+(reference src/part_file.rs), output images (src/main.rs:161-162), the progress bar
+(src/progress.rs) and the argument handling of bin/raytracer (struct Opt, src/main.rs:32-71).
+The reference has no tests for these; the expectations below restate its format strings."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "bin", "raytracer")
+
+
+@pytest.fixture
+def in_tmp(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    return tmp_path
+
+
+def _rows(h, w, seed=0):
+    return np.random.default_rng(seed).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+
+
+# ------------------------------------------------------------------ part files
+def test_part_file_bytes_and_round_trip(in_tmp):
+    h, w = 5, 4
+    rows = _rows(h, w)
+    pf = rt.PartFile("some/dir/out.png", w, h)
+    assert pf.path == "out.png.0.PART"  # basename of the image, in the working directory
+    for j in (4, 2, 0):
+        pf.write(j, rows[j])
+    pf.finish(remove=False)
+    raw = open("out.png.0.PART", "rb").read()
+    expect = b"4 5\n" + b"".join(b"L%d " % j + rows[j].tobytes() + b"\n" for j in (4, 2, 0))
+    assert raw == expect
+    got, present = rt.read_part_file("out.png.0.PART", h, w)
+    assert present.tolist() == [True, False, True, False, True]
+    assert np.array_equal(got[present], rows[present])
+
+
+def test_part_file_picks_first_free_number_and_remove(in_tmp):
+    a = rt.PartFile("img.ppm", 2, 2)
+    b = rt.PartFile("img.ppm", 2, 2)
+    assert (a.path, b.path) == ("img.ppm.0.PART", "img.ppm.1.PART")
+    a.finish(remove=True)
+    assert not os.path.exists("img.ppm.0.PART") and os.path.exists("img.ppm.1.PART")
+    c = rt.PartFile("img.ppm", 2, 2)
+    assert c.path == "img.ppm.0.PART"
+    b.finish(remove=True)
+    c.finish(remove=True)
+    assert os.listdir(".") == []
+
+
+def test_part_file_rows_may_contain_newlines_and_L(in_tmp):
+    h, w = 3, 2
+    rows = np.full((h, w, 3), ord("\n"), dtype=np.uint8)
+    rows[1] = ord("L")
+    pf = rt.PartFile("x.png", w, h)
+    for j in range(h):
+        pf.write(j, rows[j])
+    pf.finish(False)
+    got, present = rt.read_part_file(pf.path, h, w)
+    assert present.all() and np.array_equal(got, rows)
+
+
+def test_part_file_dimension_mismatch(in_tmp):
+    pf = rt.PartFile("x.png", 4, 5)
+    pf.finish(False)
+    with pytest.raises(rt.RtError, match="Image dimensions expected to be 8x5, but recovery file says they're 4x5"):
+        rt.read_part_file(pf.path, 5, 8)
+
+
+@pytest.mark.parametrize(
+    "tail, message",
+    [
+        (b"X1 " + b"\0" * 12 + b"\n", "Missing leading L"),
+        (b"L1 " + b"\0" * 5, "failed to fill whole buffer"),
+        (b"L1 " + b"\0" * 12 + b"X", "Missing newline on line 1"),
+        (b"L1 " + b"\0" * 12, "failed to fill whole buffer"),
+        (b"Lx " + b"\0" * 12 + b"\n", "invalid digit found in string"),
+        (b"L7 " + b"\0" * 12 + b"\n", "out of range"),
+    ],
+)
+def test_part_file_corruption(in_tmp, tail, message):
+    h, w = 3, 4
+    rows = _rows(h, w, 1)
+    good = b"4 3\n" + b"L2 " + rows[2].tobytes() + b"\n"
+    open("c.PART", "wb").write(good + tail)
+    with pytest.raises(rt.RtError, match=message):
+        rt.read_part_file("c.PART", h, w)
+    got, present = rt.read_part_file("c.PART", h, w, recover_corrupt=True)
+    # everything before the bad record survives; a record whose row was read completely but whose
+    # newline is missing is kept, as the reference stores the row before checking the newline
+    assert present[2] and np.array_equal(got[2], rows[2])
+    assert present.sum() == (2 if message.startswith("Missing newline") or tail == b"L1 " + b"\0" * 12 else 1)
+
+
+def test_part_file_header_errors(in_tmp):
+    open("e.PART", "wb").write(b"")
+    with pytest.raises(rt.RtError, match="Reading width"):
+        rt.read_part_file("e.PART", 2, 2)
+    open("e.PART", "wb").write(b"2 ")
+    with pytest.raises(rt.RtError, match="Reading height"):
+        rt.read_part_file("e.PART", 2, 2)
+    with pytest.raises(rt.RtError, match="cannot open"):
+        rt.read_part_file("missing.PART", 2, 2)
+
+
+# ------------------------------------------------------------------ images
+def _decode_png(raw):
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        (n,) = struct.unpack(">I", raw[pos:pos + 4])
+        kind, data = raw[pos + 4:pos + 8], raw[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(kind + data)
+        chunks.append((kind, data))
+        pos += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, ctype, comp, filt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, ctype, comp, filt, lace) == (8, 2, 0, 0, 0)
+    lines = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(h, 1 + 3 * w)
+    assert (lines[:, 0] == 0).all()
+    return lines[:, 1:].reshape(h, w, 3)
+
+
+def test_save_png_ppm_bmp(in_tmp):
+    img = _rows(7, 5, 2)
+    rt.save_image("a.png", img)
+    assert np.array_equal(_decode_png(open("a.png", "rb").read()), img)
+    rt.save_image("a.ppm", img)
+    assert open("a.ppm", "rb").read() == b"P6\n5 7\n255\n" + img.tobytes()
+    rt.save_image("a.BMP", img)
+    raw = open("a.BMP", "rb").read()
+    assert raw[:2] == b"BM" and struct.unpack("<I", raw[2:6])[0] == len(raw)
+    w, h, planes, bpp = struct.unpack("<iiHH", raw[18:30])
+    assert (w, h, planes, bpp) == (5, 7, 1, 24)
+    stride = 16
+    body = np.frombuffer(raw[54:], dtype=np.uint8).reshape(7, stride)[:, :15].reshape(7, 5, 3)
+    assert np.array_equal(body[::-1, :, ::-1], img)
+
+
+def test_save_unknown_extension(in_tmp):
+    with pytest.raises(rt.RtError, match="image format"):
+        rt.save_image("a.xyz", _rows(2, 2))
+    assert not os.path.exists("a.xyz")
+
+
+# ------------------------------------------------------------------ progress bar
+def _bar_output(length, glyphs, total, updates, clear=False, label="Rendering"):
+    r, w = os.pipe()
+    bar = rt.ProgressBar(length, label, glyphs, 100, total, fd=w)
+    for _ in range(updates):
+        bar.update()
+    if clear:
+        bar.clear()
+    bar.close()
+    os.close(w)
+    with os.fdopen(r, "rb") as f:
+        return f.read().decode("utf-8")
+
+
+def test_progress_bar_frames():
+    # length 34 - len("Rendering") - 15 = 10 cells; 3 glyphs -> 2 sub-steps per cell
+    frames = _bar_output(34, " .:", 20, 20).split("\r")[1:]
+    assert len(frames) == 20
+    assert frames[0] == "Rendering: [.         ]  0:00:00 "  # progress 1 of 20 sub-steps: the half glyph
+    assert frames[1] == "Rendering: [:         ]  0:00:00 "
+    assert frames[9] == "Rendering: [:::::     ]  0:00:00 "
+    assert frames[19] == "Rendering: [::::::::::]  0:00:00 "
+    # 40 updates over 20 sub-steps: integer division, as in the reference
+    frames = _bar_output(34, " .:", 40, 4).split("\r")[1:]
+    assert frames[0] == "Rendering: [          ]  0:00:00 "
+    assert frames[1] == "Rendering: [.         ]  0:00:00 "
+    assert frames[2] == "Rendering: [.         ]  0:00:00 "
+    assert frames[3] == "Rendering: [:         ]  0:00:00 "
+
+
+def test_progress_bar_unicode_glyphs_and_clear():
+    out = _bar_output(34, " -=≡", 10, 1, clear=True)
+    frames = out.split("\r")
+    assert frames[1] == "Rendering: [≡" + " " * 9 + "]  0:00:00 "
+    assert frames[2] == " " * (34 + len("Rendering") + 12) and frames[3] == ""
+    frames = _bar_output(34, " -=≡", 30, 2).split("\r")[1:]
+    assert frames[0].startswith("Rendering: [-") and frames[1].startswith("Rendering: [=")
+
+
+# ------------------------------------------------------------------ command line (no GPU needed for these)
+def _cli(*args, cwd=None):
+    return subprocess.run([CLI, *args], capture_output=True, text=True, cwd=cwd, timeout=60)
+
+
+def test_cli_help_version_and_usage_errors(in_tmp):
+    assert os.path.exists(CLI), "bin/raytracer is not built (make)"
+    r = _cli("--help")
+    assert r.returncode == 0
+    for flag in ("--width", "--ray-samples", "--max-bounces", "--quiet", "--ascii-symbols-only", "--recover-from",
+                 "--recover-corrupt", "--progress-bar-len", "--progress-bar-samples", "--no-part-file"):
+        assert flag in r.stdout
+    assert _cli("-V").stdout.startswith("raytracer ")
+    r = _cli()
+    assert r.returncode == 1 and "<input-file>" in r.stderr and "<output-file>" in r.stderr
+    r = _cli("a.json5")
+    assert r.returncode == 1 and "<output-file>" in r.stderr and "<input-file>" not in r.stderr.split("USAGE")[0]
+    r = _cli("a.json5", "b.png", "--frobnicate")
+    assert r.returncode == 1 and "--frobnicate" in r.stderr
+    r = _cli("a.json5", "b.png", "-w", "12x")
+    assert r.returncode == 1 and "invalid digit" in r.stderr
+    r = _cli("a.json5", "b.png", "-s")
+    assert r.returncode == 1 and "requires a value" in r.stderr
+    assert os.listdir(".") == []
+
+
+def test_cli_scene_and_part_file_errors_leave_no_part_file(in_tmp):
+    r = _cli("missing.json5", "out.png")
+    assert r.returncode == 1 and r.stderr.startswith("Error: ")
+    scene = os.path.join(ROOT, "examples", "cornell.json5")
+    open("bad.PART", "wb").write(b"10 10\n")
+    r = _cli(scene, "out.png", "-w", "32", "-r", "bad.PART")
+    assert r.returncode == 1 and "Image dimensions expected to be 32x32" in r.stderr
+    assert sorted(os.listdir(".")) == ["bad.PART"]
