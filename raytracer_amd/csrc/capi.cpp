@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -224,7 +225,7 @@ struct Engine : EngineBase {
     DevBuf<rtd::DMaterial<T>> materials;
     DevBuf<rtd::DImage> images;
     DevBuf<uint8_t> texels;
-    DevBuf<int32_t> top_list;
+    DevBuf<int32_t> top_list, sweep;
     DevBuf<unsigned char> small_blob;
     rtd::DSmallScene small;
     // work buffers
@@ -379,6 +380,7 @@ struct Engine : EngineBase {
         cvt3(S.sky.colour0, d.sky.colour0); cvt3(S.sky.colour1, d.sky.colour1);
         stack_depth = d.stack_depth;
         build_small_scene(d);
+        build_sweep(d);
         have_scene = true;
     }
 
@@ -448,6 +450,43 @@ struct Engine : EngineBase {
         n.child[1] = rtd::RT_EMPTY;
         out[(size_t)me] = n;
         return me;
+    }
+
+    // Worlds of a few objects are not walked as a tree: the leaves of the world BVH are listed in
+    // the reference's depth-first order (left child first, src/hitting.rs:211-229) and every ray
+    // tests all of them in that order (kernels.hip, WALK_SWEEP).  Subtrees under a zero-thickness
+    // interior box are left out, as in build_nodes2: the reference culls them for every ray.
+    // RT_SWEEP_MAX (environment, default 12) is the largest leaf count handled this way; 0 disables.
+    void build_sweep(const rt_scene_desc& d) {
+        S.sweep = nullptr;
+        S.n_sweep = 0;
+        if (d.tlas_root < 0) return;
+        long limit = 12;
+        if (const char* e = std::getenv("RT_SWEEP_MAX")) limit = std::strtol(e, nullptr, 10);
+        std::vector<int32_t> order, todo{d.tlas_root};
+        while (!todo.empty()) {
+            const rt_node& nd = d.nodes[todo.back()];
+            todo.pop_back();
+            if (nd.left < 0) {
+                // a mesh is better entered through its own box in the tree walk (measured: knight 85 -> 114 ms)
+                if (d.objects[-1 - nd.left].kind == RT_OBJ_BLAS) return;
+                order.push_back(-1 - nd.left);
+                if ((long)order.size() > limit) return;
+                continue;
+            }
+            bool well_formed = true, flat = false;
+            for (int k = 0; k < 3; k++) {
+                if (!(nd.lo[k] <= nd.hi[k]) || !std::isfinite(nd.lo[k]) || !std::isfinite(nd.hi[k])) well_formed = false;
+                if (nd.lo[k] == nd.hi[k]) flat = true;
+            }
+            if (well_formed && flat) continue;
+            todo.push_back(nd.right);  // popped after the whole left subtree
+            todo.push_back(nd.left);
+        }
+        if (order.empty()) return;
+        sweep.upload(order);
+        S.sweep = sweep.p;
+        S.n_sweep = (int32_t)order.size();
     }
 
     // Packs the traversal records of a small scene into one blob for LDS staging (k_extend<.., true>).
@@ -603,6 +642,9 @@ struct Engine : EngineBase {
         HIP_CHECK(hipMemsetAsync(ray_total.p, 0, sizeof(unsigned long long), stream));
         size_t ev = 0;
         const bool timing = stats != nullptr;
+        // RT_FUSE=0 (environment) keeps the two-kernel bounce (extend, then shade) for A/B measurements.
+        const char* fuse_env = std::getenv("RT_FUSE");
+        const bool fused = !(fuse_env && fuse_env[0] == '0');
         std::vector<std::pair<size_t, int>> spans;  // (first event index, 0 = extend / 1 = shade)
         hipEvent_t ev_begin = event(ev++), ev_end = event(ev++);
         if (timing) HIP_CHECK(hipEventRecord(ev_begin, stream));
@@ -625,14 +667,20 @@ struct Engine : EngineBase {
                     spans.push_back({ev, 0});
                     HIP_CHECK(hipEventRecord(event(ev), stream));
                 }
-                rtd::Launch<T>::extend(S, small, B, queue(in), hits(false), nullptr, nullptr, depth, tile_offsets.p, n_tiles,
-                                       stack_depth, grid, stream);
-                if (timing) {
-                    HIP_CHECK(hipEventRecord(event(ev + 1), stream));
-                    spans.push_back({ev + 1, 1});
+                if (fused) {  // one launch per bounce; its time is reported as ms_extend
+                    rtd::Launch<T>::bounce(S, small, B, queue(in), queue(out), sample_rgb.p, depth, max_bounces,
+                                           tile_offsets.p, tile_counts[out].p, n_tiles, stack_depth, grid, stream);
+                    if (timing) HIP_CHECK(hipEventRecord(event(ev + 1), stream));
+                } else {
+                    rtd::Launch<T>::extend(S, small, B, queue(in), hits(false), nullptr, nullptr, depth, tile_offsets.p,
+                                           n_tiles, stack_depth, grid, stream);
+                    if (timing) {
+                        HIP_CHECK(hipEventRecord(event(ev + 1), stream));
+                        spans.push_back({ev + 1, 1});
+                    }
+                    rtd::Launch<T>::shade(S, B, queue(in), hits(false), queue(out), sample_rgb.p, depth, max_bounces,
+                                          tile_offsets.p, tile_counts[out].p, n_tiles, grid, stream);
                 }
-                rtd::Launch<T>::shade(S, B, queue(in), hits(false), queue(out), sample_rgb.p, depth, max_bounces,
-                                      tile_offsets.p, tile_counts[out].p, n_tiles, grid, stream);
                 // offsets of the queue just written, clear the counts of the other one, rays += survivors
                 rtd::launch_scan_tiles(tile_counts[out].p, n_tiles, tile_offsets.p, tile_counts[in].p, counts.p,
                                        ray_total.p, stream);

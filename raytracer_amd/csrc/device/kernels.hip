@@ -123,6 +123,9 @@ template <typename T> __device__ V3<T> random_in_unit_sphere(Rng<T>& rng) {  // 
         T py = rng.range((T)-1.0, (T)1.0);
         T pz = rng.range((T)-1.0, (T)1.0);
         V3<T> p = mk(px, py, pz);
+#ifdef RT_EXP_NOLOOP  // timing experiment only: wrong distribution
+        return p;
+#endif
         if (length_squared(p) <= (T)1.0) return p;
     }
 }
@@ -147,8 +150,28 @@ __device__ __forceinline__ void path_ids(const DBatch& B, uint32_t pid, uint32_t
 }
 
 // ------------------------------------------------------------------ primitives
+// Record loads.  UNIFORM = the index is the same for every lane of the wave (sweep traversal): the
+// load goes through the constant address space, which the compiler turns into scalar loads
+// (s_load_dwordx8/x16 through the scalar cache) - the record lands in SGPRs, costs no VGPRs and no
+// vector-memory issue slot.  Valid because the scene is immutable while kernels run.
+template <bool UNIFORM, typename P>
+__device__ __forceinline__ P rec(const P* p) {
+    if constexpr (UNIFORM) {
+        static_assert(sizeof(P) % 4 == 0, "records are whole dwords");
+        typedef const __attribute__((address_space(4))) uint32_t* const_dwords;
+        const_dwords src = (const_dwords)(uintptr_t)p;
+        P out;
+        uint32_t* dst = (uint32_t*)&out;
+#pragma unroll
+        for (unsigned k = 0; k < sizeof(P) / 4; k++) dst[k] = src[k];
+        return out;
+    } else {
+        return *p;
+    }
+}
+
 template <typename T>
-__device__ __forceinline__ Ray<T> to_object_space(const DXform<T>& X, const Ray<T>& r) {
+__device__ __forceinline__ Ray<T> to_object_space(const DXform<T> X, const Ray<T>& r) {
     // One rigid map for a whole chain of Translate/Rotate*::hit (src/transforms.rs:22-23,
     // 103-112, 194-203, 285-294); Ray::new re-normalises the direction (src/math.rs:208-214).
     Ray<T> q;
@@ -187,7 +210,7 @@ __device__ __forceinline__ bool distance_to_sphere(const Ray<T>& ray, V3<T> cent
 }
 
 template <typename T>
-__device__ __forceinline__ V3<T> moving_centre(const DMovingSphere<T>& s, T time) {  // src/objects.rs:94-97
+__device__ __forceinline__ V3<T> moving_centre(const DMovingSphere<T> s, T time) {  // src/objects.rs:94-97
     return ld3(s.centre0) + ((time - s.time0) / (s.time1 - s.time0)) * (ld3(s.centre1) - ld3(s.centre0));
 }
 
@@ -210,7 +233,7 @@ __device__ __forceinline__ bool line_plane_collision(V3<T> la, V3<T> lab, V3<T> 
 
 // XYRect / XZRect / YZRect::hit, src/objects.rs:224-244, 288-308, 352-372.
 template <typename T>
-__device__ __forceinline__ bool rect_hit(const DRect<T>& q, const Ray<T>& r, T min_dist, T max_dist, T* t_out) {
+__device__ __forceinline__ bool rect_hit(const DRect<T> q, const Ray<T>& r, T min_dist, T max_dist, T* t_out) {
     int axis = q.axis;
     int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
     T t = (q.k - comp(r.o, axis)) / comp(r.d, axis);
@@ -223,9 +246,48 @@ __device__ __forceinline__ bool rect_hit(const DRect<T>& q, const Ray<T>& r, T m
     return true;
 }
 
+// The same test for a rect whose record is wave-uniform (sweep traversal): the axis is then known
+// per wave, so the ray components are picked at compile time (comp() costs 24 v_cndmask per f64
+// rect test) and the comparisons of rect_hit are evaluated without branches.  NaN behaves as in
+// rect_hit: every `<` / `>` is false and `t != t` rejects.
+template <int I, typename T> __device__ __forceinline__ T cget(const V3<T>& a) { return I == 0 ? a.x : I == 1 ? a.y : a.z; }
+
+template <typename T, int AXIS>
+__device__ __forceinline__ void rect_axis_test(const DRect<T>& q, int index, const Ray<T>& r, T min_dist, T max_dist,
+                                               bool& have, T& bt, int& bi) {
+    constexpr int IA = AXIS == 0 ? 1 : 0, IB = AXIS == 2 ? 1 : 2;
+    const T t = (q.k - cget<AXIS>(r.o)) / cget<AXIS>(r.d);
+    const T a = cget<IA>(r.o) + t * cget<IA>(r.d);
+    const T b = cget<IB>(r.o) + t * cget<IB>(r.d);
+    const bool miss = (t < min_dist) | (t > max_dist) | (a < q.a0) | (a > q.a1) | (b < q.b0) | (b > q.b1) | (t != t);
+    const bool better = !miss & (!have | (t < bt));
+    bt = better ? t : bt;
+    bi = better ? index : bi;
+    have = have | !miss;
+}
+
+template <typename T>
+__device__ __forceinline__ bool rects_hit_uniform(const DScene<T>& S, const Ray<T>& r, int first, int count, T min_dist,
+                                                  T max_dist, T* t_out, int* prim_out) {
+    bool have = false;
+    T bt = 0;
+    int bi = -1;
+    for (int k = 0; k < count; k++) {
+        const DRect<T> q = rec<true>(&S.rects[first + k]);
+        switch (q.axis) {  // a scalar branch
+            case 0: rect_axis_test<T, 0>(q, first + k, r, min_dist, max_dist, have, bt, bi); break;
+            case 1: rect_axis_test<T, 1>(q, first + k, r, min_dist, max_dist, have, bt, bi); break;
+            default: rect_axis_test<T, 2>(q, first + k, r, min_dist, max_dist, have, bt, bi); break;
+        }
+    }
+    *t_out = bt;
+    *prim_out = bi;
+    return have;
+}
+
 // Vec<Arc<dyn Hittable>>::hit over a Block's sides / a Spotlight's panes (src/hitting.rs:88-104):
 // every element sees the same [min,max]; strict < keeps the first of equal distances.
-template <typename T>
+template <typename T, bool UNIFORM>
 __device__ __forceinline__ bool rects_hit(const DScene<T>& S, const Ray<T>& r, int first, int count, T min_dist,
                                           T max_dist, T* t_out, int* prim_out) {
     bool have = false;
@@ -233,7 +295,7 @@ __device__ __forceinline__ bool rects_hit(const DScene<T>& S, const Ray<T>& r, i
     int bi = -1;
     for (int k = 0; k < count; k++) {
         T t;
-        if (rect_hit(S.rects[first + k], r, min_dist, max_dist, &t)) {
+        if (rect_hit(rec<UNIFORM>(&S.rects[first + k]), r, min_dist, max_dist, &t)) {
             if (!have || t < bt) {
                 bt = t;
                 bi = first + k;
@@ -247,7 +309,7 @@ __device__ __forceinline__ bool rects_hit(const DScene<T>& S, const Ray<T>& r, i
 }
 
 template <typename T>
-__device__ __forceinline__ bool triangle_hit(const DTriangle<T>& tr, const Ray<T>& r, T min_dist, T max_dist, T* t_out) {
+__device__ __forceinline__ bool triangle_hit(const DTriangle<T> tr, const Ray<T>& r, T min_dist, T max_dist, T* t_out) {
     // src/objects.rs:537-558
     V3<T> s;
     if (!line_plane_collision(r.o, r.d, ld3(tr.point), ld3(tr.vec1), ld3(tr.vec2), &s)) return false;
@@ -393,27 +455,27 @@ struct Winner {
 };
 
 // Hittable::hit of one non-medium object instance with bounds [min_dist, max_dist].
-template <typename T>
+template <typename T, bool UNIFORM>
 __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist,
                                   Stack st, int sp, T* t_out, int* prim_out) {
-    const DObject ob = S.objects[oi];
+    const DObject ob = rec<UNIFORM>(&S.objects[oi]);
     Ray<T> r = world_ray;
-    if (ob.xform >= 0) r = to_object_space(S.xforms[ob.xform], world_ray);
+    if (ob.xform >= 0) r = to_object_space(rec<UNIFORM>(&S.xforms[ob.xform]), world_ray);
     switch (ob.kind) {
         case RT_OBJ_SPHERE: {
-            const DSphere<T>& s = S.spheres[ob.first];
+            const DSphere<T> s = rec<UNIFORM>(&S.spheres[ob.first]);
             *prim_out = ob.first;
             return distance_to_sphere(r, ld3(s.centre), s.radius, min_dist, max_dist, t_out);
         }
         case RT_OBJ_MOVING_SPHERE: {
-            const DMovingSphere<T>& s = S.moving_spheres[ob.first];
+            const DMovingSphere<T> s = rec<UNIFORM>(&S.moving_spheres[ob.first]);
             *prim_out = ob.first;
             return distance_to_sphere(r, moving_centre(s, r.time), s.radius, min_dist, max_dist, t_out);
         }
-        case RT_OBJ_RECTS: return rects_hit(S, r, ob.first, ob.count, min_dist, max_dist, t_out, prim_out);
-        case RT_OBJ_TRIANGLE: *prim_out = ob.first; return triangle_hit(S.triangles[ob.first], r, min_dist, max_dist, t_out);
+        case RT_OBJ_RECTS: return rects_hit<T, UNIFORM>(S, r, ob.first, ob.count, min_dist, max_dist, t_out, prim_out);
+        case RT_OBJ_TRIANGLE: *prim_out = ob.first; return triangle_hit(rec<UNIFORM>(&S.triangles[ob.first]), r, min_dist, max_dist, t_out);
         case RT_OBJ_PLANE: {  // src/objects.rs:599-606
-            const DPlane<T>& p = S.planes[ob.first];
+            const DPlane<T> p = rec<UNIFORM>(&S.planes[ob.first]);
             V3<T> s;
             if (!line_plane_collision(r.o, r.d, ld3(p.point), ld3(p.vec1), ld3(p.vec2), &s)) return false;
             if (s.x < min_dist || s.x > max_dist) return false;
@@ -427,27 +489,36 @@ __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& worl
 }
 
 // Hittable::hit of any object instance, constant media included (src/objects.rs:404-448).
-template <typename T>
+// The stream of a path's draws is named by (pixel, sample); both come from the path id by an
+// integer division, which only the rare constant-medium draw needs: computed there.
+struct PathRef {
+    const DBatch* batch;
+    uint32_t pid;
+};
+
+template <typename T, bool UNIFORM>
 __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist, Stack st,
-                           int sp, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t depth, T* t_out,
-                           int* prim_out) {
-    const DObject ob = S.objects[oi];
-    if (ob.kind != RT_OBJ_MEDIUM) return simple_object_hit(S, oi, world_ray, min_dist, max_dist, st, sp, t_out, prim_out);
-    const DMedium<T>& md = S.media[ob.first];
+                           int sp, PathRef path, uint32_t depth, T* t_out, int* prim_out) {
+    const DObject ob = rec<UNIFORM>(&S.objects[oi]);
+    if (ob.kind != RT_OBJ_MEDIUM) return simple_object_hit<T, UNIFORM>(S, oi, world_ray, min_dist, max_dist, st, sp, t_out, prim_out);
+    const DMedium<T> md = rec<UNIFORM>(&S.media[ob.first]);
     Ray<T> r = world_ray;
-    if (ob.xform >= 0) r = to_object_space(S.xforms[ob.xform], world_ray);
+    if (ob.xform >= 0) r = to_object_space(rec<UNIFORM>(&S.xforms[ob.xform]), world_ray);
     const T inf = Lim<T>::inf();
     T t1, t2;
     int ignore;
-    if (!simple_object_hit(S, md.boundary_object, r, -inf, inf, st, sp, &t1, &ignore)) return false;
-    if (!simple_object_hit(S, md.boundary_object, r, t1 + (T)0.0001, inf, st, sp, &t2, &ignore)) return false;
+    // (the second query runs only in the lanes whose first one hit, so it is not wave-uniform)
+    if (!simple_object_hit<T, UNIFORM>(S, md.boundary_object, r, -inf, inf, st, sp, &t1, &ignore)) return false;
+    if (!simple_object_hit<T, UNIFORM>(S, md.boundary_object, r, t1 + (T)0.0001, inf, st, sp, &t2, &ignore)) return false;
     if (t1 < min_dist) t1 = min_dist;
     if (t2 > max_dist) t2 = max_dist;
     if (t1 >= t2) return false;
     if (t1 < (T)0.0) t1 = (T)0.0;
     T ray_length = length(r.d);
     T distance_inside_boundary = (t2 - t1) * ray_length;
-    Rng<T> rng(seed, DOMAIN_MEDIUM | md.rng_key, pixel, sample, depth);
+    uint32_t pixel, sample;
+    path_ids(*path.batch, path.pid, &pixel, &sample);
+    Rng<T> rng(path.batch->seed, DOMAIN_MEDIUM | md.rng_key, pixel, sample, depth);
     T hit_distance = md.neg_inv_density * log(rng.next());
     if (hit_distance > distance_inside_boundary) return false;
     *t_out = t1 + hit_distance / ray_length;
@@ -457,21 +528,55 @@ __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, 
 
 // world.hit(ray, min, max): the top-level Vec (src/hitting.rs:188-194 -> :88-104) over the
 // world BVH and the unbounded objects; inside the BVH, BVHNode::hit (:211-229).
-template <typename T, bool OWN_BOX>
-__device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T max_dist, Stack st, uint64_t seed,
-                            uint32_t pixel, uint32_t sample, uint32_t depth, T* t_out, Winner* w_out) {
+enum { WALK_NODE2 = 0, WALK_OWN_BOX_LDS = 1, WALK_SWEEP = 2 };
+
+template <typename T, int MODE>
+__device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T max_dist, Stack st, PathRef path,
+                            uint32_t depth, T* t_out, Winner* w_out) {
+    constexpr bool UNI = MODE == WALK_SWEEP;  // the top-level list is walked in step by all lanes
     bool have = false;
     T best_t = 0;
     Winner best{-1, -1};
     for (int e = 0; e < S.n_top; e++) {
-        int entry = S.top_list[e];
+        int entry = UNI ? rec<true>(&S.top_list[e]) : S.top_list[e];
         bool found = false;
         T t = 0;
         Winner w{-1, -1};
         if (entry != RT_TOP_BVH) {
-            found = object_hit(S, entry, ray, min_dist, max_dist, st, 0, seed, pixel, sample, depth, &t, &w.prim);
+            found = object_hit<T, UNI>(S, entry, ray, min_dist, max_dist, st, 0, path, depth, &t, &w.prim);
             w.obj = entry;
-        } else if (OWN_BOX) {
+        } else if (MODE == WALK_SWEEP) {
+            // Worlds of a few objects: no tree walk at all.  The leaves of the reference BVH are visited
+            // in its depth-first order (left child first) with the same shrinking bound and the same
+            // "t <= bound: the later leaf wins" rule, so the winner is the one BVHNode::hit returns
+            // (src/hitting.rs:211-229); the boxes the reference tests on the way only ever skip leaves
+            // that cannot be hit inside the bound.  Every lane of the wave tests the same object in the
+            // same iteration: no divergence, no stack, and the object / transform / primitive records
+            // come in through scalar loads.
+            T bound = max_dist;
+            for (int k = 0; k < S.n_sweep; k++) {
+                const int oi = rec<true>(&S.sweep[k]);
+                const DObject ob = rec<true>(&S.objects[oi]);
+                T th = 0;
+                int prim = -1;
+                bool hit;
+                if (ob.kind == RT_OBJ_RECTS) {  // walls, Blocks, Spotlights: the lean path (scalar branches only)
+                    if (ob.xform >= 0) {
+                        const Ray<T> r = to_object_space(rec<true>(&S.xforms[ob.xform]), ray);
+                        hit = rects_hit_uniform(S, r, ob.first, ob.count, min_dist, bound, &th, &prim);
+                    } else {
+                        hit = rects_hit_uniform(S, ray, ob.first, ob.count, min_dist, bound, &th, &prim);
+                    }
+                } else {
+                    hit = object_hit<T, true>(S, oi, ray, min_dist, bound, st, 0, path, depth, &th, &prim);
+                }
+                bound = hit ? th : bound;
+                w.obj = hit ? oi : w.obj;
+                w.prim = hit ? prim : w.prim;
+                found = found | hit;
+            }
+            t = bound;
+        } else if (MODE == WALK_OWN_BOX_LDS) {
             // Small worlds (staged in LDS): reference-shaped nodes, each with its own f64 box.  Nearly
             // every ray of a closed box visits nearly every node, so the lanes of a wave stay in step.
             V3<T> inv_d = mk((T)1.0 / ray.d.x, (T)1.0 / ray.d.y, (T)1.0 / ray.d.z);
@@ -485,7 +590,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                     int oi = -1 - left;
                     T th;
                     int prim;
-                    if (object_hit(S, oi, ray, min_dist, bound, st, sp, seed, pixel, sample, depth, &th, &prim)) {
+                    if (object_hit<T, false>(S, oi, ray, min_dist, bound, st, sp, path, depth, &th, &prim)) {
                         bound = th;
                         w.obj = oi;
                         w.prim = prim;
@@ -516,7 +621,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                     const int oi = -1 - next;
                     T th;
                     int prim;
-                    if (object_hit(S, oi, ray, min_dist, bound, st, sp, seed, pixel, sample, depth, &th, &prim)) {
+                    if (object_hit<T, false>(S, oi, ray, min_dist, bound, st, sp, path, depth, &th, &prim)) {
                         bound = th;
                         bound32 = round_up(th);
                         w.obj = oi;
@@ -581,7 +686,7 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
     sf.u = 0;
     sf.v = 0;
     sf.sub = 0;
-    bool medium = false;
+    bool medium = false, unit_already = false;
     switch (ob.kind) {
         case RT_OBJ_SPHERE: {
             const DSphere<T>& s = S.spheres[w.prim];
@@ -609,6 +714,7 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
             sf.v = (b - q.b0) / (q.b1 - q.b0);
             T s = q.facing_positive ? (T)1.0 : (T)-1.0;
             outward = mk(axis == 0 ? s : (T)0.0, axis == 1 ? s : (T)0.0, axis == 2 ? s : (T)0.0);
+            unit_already = true;  // (+-1, 0, 0) / sqrt(1) is itself, bit for bit: skip HitRecord::new's unit_vector
             sf.material = q.material;
             sf.owner = q.owner;
             sf.sub = q.sub;
@@ -653,7 +759,7 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
         sf.normal = outward;
     } else {
         sf.front_face = dot(r.d, outward) < (T)0.0;
-        V3<T> n = unit_vector(outward);
+        V3<T> n = unit_already ? outward : unit_vector(outward);
         sf.normal = sf.front_face ? n : -n;
     }
     if (ob.xform >= 0) sf.normal = rotate_to_world(S.xforms[ob.xform], sf.normal);
@@ -762,32 +868,37 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<
     q.pid[pid] = pid;
 }
 
+// Copies a small scene's traversal records into LDS (all threads of the block) and points S at them.
+template <typename T>
+__device__ __forceinline__ void stage_small_scene(DScene<T>& S, const DSmallScene& small, uint4* lds_scene) {
+    const uint4* src = (const uint4*)small.blob;
+    for (uint32_t k = threadIdx.x; k < small.bytes / 16; k += BLOCK) lds_scene[k] = src[k];
+    __syncthreads();
+    const unsigned char* base = (const unsigned char*)lds_scene;
+    S.nodes = (const DNode<T>*)(base + small.off[0]);
+    S.objects = (const DObject*)(base + small.off[1]);
+    S.xforms = (const DXform<T>*)(base + small.off[2]);
+    S.spheres = (const DSphere<T>*)(base + small.off[3]);
+    S.moving_spheres = (const DMovingSphere<T>*)(base + small.off[4]);
+    S.rects = (const DRect<T>*)(base + small.off[5]);
+    S.planes = (const DPlane<T>*)(base + small.off[6]);
+    S.media = (const DMedium<T>*)(base + small.off[7]);
+    S.top_list = (const int32_t*)(base + small.off[8]);
+}
+
 // LDS_SCENE: scenes whose acceleration structure and primitives (everything but triangles,
 // materials and texels) fit in RT_LDS_SCENE_BYTES are copied into LDS by every block once and
 // traversed from there: the traversal is a chain of dependent record fetches (node -> object ->
 // transform -> primitive), and an LDS read returns in ~1/5 of the time of an L2 hit.
-template <typename T, int STACK, bool LDS_SCENE>
+template <typename T, int STACK, int MODE>
 __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, DSmallScene small, DBatch B, DQueue<T> q, DHits<T> h, const T* tmin_arr,
                                                    const T* tmax_arr, uint32_t depth,
                                                    const uint32_t* __restrict__ tile_offsets, uint32_t n_tiles) {
     __shared__ int32_t lds_stack[STACK * BLOCK];
+    constexpr bool LDS_SCENE = MODE == WALK_OWN_BOX_LDS;
     __shared__ uint4 lds_scene[LDS_SCENE ? RT_LDS_SCENE_BYTES / 16 : 1];
     Stack st{lds_stack + threadIdx.x, BLOCK};
-    if (LDS_SCENE) {
-        const uint4* src = (const uint4*)small.blob;
-        for (uint32_t k = threadIdx.x; k < small.bytes / 16; k += BLOCK) lds_scene[k] = src[k];
-        __syncthreads();
-        const unsigned char* base = (const unsigned char*)lds_scene;
-        S.nodes = (const DNode<T>*)(base + small.off[0]);
-        S.objects = (const DObject*)(base + small.off[1]);
-        S.xforms = (const DXform<T>*)(base + small.off[2]);
-        S.spheres = (const DSphere<T>*)(base + small.off[3]);
-        S.moving_spheres = (const DMovingSphere<T>*)(base + small.off[4]);
-        S.rects = (const DRect<T>*)(base + small.off[5]);
-        S.planes = (const DPlane<T>*)(base + small.off[6]);
-        S.media = (const DMedium<T>*)(base + small.off[7]);
-        S.top_list = (const int32_t*)(base + small.off[8]);
-    }
+    if (LDS_SCENE) stage_small_scene(S, small, lds_scene);
     const uint32_t total = tile_offsets[n_tiles];
     const uint32_t lane = threadIdx.x & 63;
     for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < total; base += gridDim.x * BLOCK) {
@@ -796,14 +907,12 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
         uint32_t tile;
         const uint32_t i = slot_of(tile_offsets, n_tiles, d, base, &tile);
         Ray<T> r = load_ray(q, i);
-        uint32_t pid = q.pid[i];
-        uint32_t pixel, sample;
-        path_ids(B, pid, &pixel, &sample);
+        const PathRef path{&B, q.pid[i]};
         T min_dist = tmin_arr ? tmin_arr[i] : (T)0.001;  // src/hitting.rs:20-21
         T max_dist = tmax_arr ? tmax_arr[i] : Lim<T>::inf();
         T t;
         Winner w;
-        if (closest_hit<T, LDS_SCENE>(S, r, min_dist, max_dist, st, B.seed, pixel, sample, depth, &t, &w)) {
+        if (closest_hit<T, MODE>(S, r, min_dist, max_dist, st, path, depth, &t, &w)) {
             Surface<T> sf = make_surface(S, r, t, w);
             h.t[i] = t;
             h.nx[i] = sf.normal.x; h.ny[i] = sf.normal.y; h.nz[i] = sf.normal.z;
@@ -844,15 +953,148 @@ __device__ __forceinline__ T reflectance(T cosine, T ref_idx) {  // src/material
     return r0 + ((T)1.0 - r0) * pow((T)1.0 - cosine, (T)5.0);
 }
 
+// One bounce of cast_ray for one path (src/hitting.rs:11-31) after its closest-hit query: adds what
+// the path sees (light / sky) to its sample, and scatters.  mf = material | front_face << 31, or
+// RT_MISS.  Returns true if the path goes on: nr is the scattered ray, thr the new throughput.
+template <typename T>
+__device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, const Ray<T>& ray, V3<T>& thr, uint32_t pid,
+                                           uint32_t mf, T t, V3<T> n, T u, T v, T* sample_rgb, uint32_t depth,
+                                           uint32_t max_bounces, Ray<T>& nr) {
+    const T PI = (T)3.14159265358979323846264338327950288;
+    bool alive = false;
+    V3<T> add = mk((T)0.0, (T)0.0, (T)0.0);
+    bool contributes = false;
+    if (mf == RT_MISS) {  // sky(ray), src/hitting.rs:29
+        V3<T> c;
+        if (S.sky.gradient) {  // src/camera.rs:78-86
+            T gradient_pos = dot(ld3(S.sky.unit_dir), unit_vector(ray.d));
+            T g = (T)0.5 * (gradient_pos + (T)1.0);
+            c = (T)1.0 * (((T)1.0 - g) * ld3(S.sky.colour0) + g * ld3(S.sky.colour1));
+        } else {
+            c = ld3(S.sky.colour);
+        }
+        add = coeff(thr, c);
+        contributes = true;
+    } else {
+        bool front = (mf & 0x80000000u) != 0;
+        int mi = (int)(mf & 0x7fffffffu);
+        V3<T> p = ray.at(t);  // HitRecord::new: intersection = ray.at(distance)
+        // emitted(): Checkered picks its part with sin(k u) sin(k v) - no PI (src/materials.rs:175-183)
+        {
+            int me = mi;
+            DMaterial<T> m = S.materials[me];
+            while (m.type == RT_MAT_CHECKERED) {
+                T sines = sin(m.param * u) * sin(m.param * v);
+                me = sines < (T)0.0 ? m.odd : m.even;
+                m = S.materials[me];
+            }
+            if (m.type == RT_MAT_DIFFUSE_LIGHT && front) {  // src/materials.rs:129-136
+                add = coeff(thr, texture_value(S, m, u, v));
+                contributes = true;
+            }
+        }
+        // scatter(): Checkered picks with sin(k PI u) sin(k PI v) (src/materials.rs:166-174)
+        DMaterial<T> m = S.materials[mi];
+        while (m.type == RT_MAT_CHECKERED) {
+            T sines = sin(m.param * PI * u) * sin(m.param * PI * v);
+            mi = sines < (T)0.0 ? m.odd : m.even;
+            m = S.materials[mi];
+        }
+        uint32_t pixel, sample;
+        path_ids(B, pid, &pixel, &sample);
+        Rng<T> rng(B.seed, DOMAIN_MATERIAL, pixel, sample, depth);
+        V3<T> attenuation = mk((T)1.0, (T)1.0, (T)1.0);
+        V3<T> dir = n;
+        bool scattered = false, metal = false;
+        switch (m.type) {
+            case RT_MAT_LAMBERTIAN: {  // src/materials.rs:27-42
+                dir = n + unit_vector(random_in_unit_sphere(rng));
+                if (near_zero(dir)) dir = n;
+                attenuation = texture_value(S, m, u, v);
+                scattered = true;
+                break;
+            }
+            case RT_MAT_METAL: {  // :53-66
+                V3<T> reflected = reflect(unit_vector(ray.d), n);
+                dir = reflected + m.param * random_in_unit_sphere(rng);
+                attenuation = ld3(m.colour);
+                metal = true;
+                scattered = true;
+                break;
+            }
+            case RT_MAT_DIELECTRIC: {  // :76-101
+                T ratio = front ? (T)1.0 / m.param : m.param;
+                V3<T> ud = unit_vector(ray.d);
+                T cos_theta = fmin(dot(-ud, n), (T)1.0);
+                T sin_theta = sqrt((T)1.0 - cos_theta * cos_theta);
+                bool cannot_refract = ratio * sin_theta > (T)1.0;
+                T random_fraction = rng.range((T)0.0, (T)1.0);
+                dir = (cannot_refract || reflectance(cos_theta, ratio) > random_fraction) ? reflect(ud, n)
+                                                                                         : refract(ud, n, ratio);
+                scattered = true;
+                break;
+            }
+            case RT_MAT_ISOTROPIC: {  // :146-153
+                dir = random_in_unit_sphere(rng);
+                attenuation = texture_value(S, m, u, v);
+                scattered = true;
+                break;
+            }
+            default: break;  // DiffuseLight::scatter -> None (:126-128)
+        }
+        // cast_ray(new_ray, .., bounces - 1) returns black once bounces hits 0 (src/hitting.rs:17-19).
+        V3<T> new_dir = unit_vector(dir);  // Ray::new normalises (src/math.rs:208-214)
+        if (metal) scattered = dot(new_dir, n) > (T)0.0;  // absorbed otherwise (src/materials.rs:61-65)
+        if (scattered && depth + 1 < max_bounces) {
+            alive = true;
+            nr.o = p;
+            nr.d = new_dir;
+            nr.time = ray.time;
+            thr = coeff(thr, attenuation);
+        }
+    }
+    if (contributes) {
+        T* dst = sample_rgb + (uint64_t)pid * 3;
+        dst[0] += add.x; dst[1] += add.y; dst[2] += add.z;
+    }
+    return alive;
+}
+
+// Compaction: the survivors of input tile t are packed at the front of output tile t.  One
+// returning atomic per wave and tile on that tile's own counter (thousands of counters spread
+// over the L2 channels; a single global counter saturates at ~90 atomics/us on MI355X).  A
+// wave's items span one tile, rarely two; lanes are placed by ballot prefix.  Every lane of the
+// wave must call this.
+template <typename T>
+__device__ __forceinline__ void compact_store(bool alive, uint32_t tile, const Ray<T>& nr, V3<T> thr, uint32_t pid,
+                                              const DQueue<T>& qout, uint32_t* tile_counts_out) {
+    const uint32_t lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(alive);
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        uint32_t t_lead = __shfl(tile, leader);
+        unsigned long long same = __ballot(alive && tile == t_lead);
+        uint32_t start = 0;
+        if ((int)lane == leader) start = atomicAdd(&tile_counts_out[t_lead], (uint32_t)__popcll(same));
+        start = __shfl(start, leader);
+        if (alive && tile == t_lead) {
+            uint32_t o = t_lead * TILE + start + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            store_ray(qout, o, nr);
+            qout.tr[o] = thr.x; qout.tg[o] = thr.y; qout.tb[o] = thr.z;
+            qout.pid[o] = pid;
+        }
+        todo &= ~same;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_shade(DScene<T> S, DBatch B, DQueue<T> qin, DHits<T> h, DQueue<T> qout,
                                                   T* sample_rgb, uint32_t depth, uint32_t max_bounces,
                                                   const uint32_t* __restrict__ tile_offsets, uint32_t* tile_counts_out,
                                                   uint32_t n_tiles) {
-    const T PI = (T)3.14159265358979323846264338327950288;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t total = tile_offsets[n_tiles];
-    // The loop bound is wave-uniform so that every lane reaches the ballots below.
+    // The loop bound is wave-uniform so that every lane reaches the ballots of compact_store.
     for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < total; base += gridDim.x * BLOCK) {
         const uint32_t d = base + lane;
         const bool valid = d < total;
@@ -867,124 +1109,59 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene<T> S, DBatch B, DQueue<T
             pid = qin.pid[i];
             thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
             uint32_t mf = h.mat_front[i];
-            V3<T> add = mk((T)0.0, (T)0.0, (T)0.0);
-            bool contributes = false;
-            if (mf == RT_MISS) {  // sky(ray), src/hitting.rs:29
-                V3<T> c;
-                if (S.sky.gradient) {  // src/camera.rs:78-86
-                    T gradient_pos = dot(ld3(S.sky.unit_dir), unit_vector(ray.d));
-                    T t = (T)0.5 * (gradient_pos + (T)1.0);
-                    c = (T)1.0 * (((T)1.0 - t) * ld3(S.sky.colour0) + t * ld3(S.sky.colour1));
-                } else {
-                    c = ld3(S.sky.colour);
-                }
-                add = coeff(thr, c);
-                contributes = true;
-            } else {
-                bool front = (mf & 0x80000000u) != 0;
-                int mi = (int)(mf & 0x7fffffffu);
-                T t = h.t[i], u = h.u[i], v = h.v[i];
-                V3<T> n = mk(h.nx[i], h.ny[i], h.nz[i]);
-                V3<T> p = ray.at(t);  // HitRecord::new: intersection = ray.at(distance)
-                // emitted(): Checkered picks its part with sin(k u) sin(k v) - no PI (src/materials.rs:175-183)
-                {
-                    int me = mi;
-                    DMaterial<T> m = S.materials[me];
-                    while (m.type == RT_MAT_CHECKERED) {
-                        T sines = sin(m.param * u) * sin(m.param * v);
-                        me = sines < (T)0.0 ? m.odd : m.even;
-                        m = S.materials[me];
-                    }
-                    if (m.type == RT_MAT_DIFFUSE_LIGHT && front) {  // src/materials.rs:129-136
-                        add = coeff(thr, texture_value(S, m, u, v));
-                        contributes = true;
-                    }
-                }
-                // scatter(): Checkered picks with sin(k PI u) sin(k PI v) (src/materials.rs:166-174)
-                DMaterial<T> m = S.materials[mi];
-                while (m.type == RT_MAT_CHECKERED) {
-                    T sines = sin(m.param * PI * u) * sin(m.param * PI * v);
-                    mi = sines < (T)0.0 ? m.odd : m.even;
-                    m = S.materials[mi];
-                }
-                uint32_t pixel, sample;
-                path_ids(B, pid, &pixel, &sample);
-                Rng<T> rng(B.seed, DOMAIN_MATERIAL, pixel, sample, depth);
-                V3<T> attenuation = mk((T)1.0, (T)1.0, (T)1.0);
-                V3<T> dir = n;
-                bool scattered = false, metal = false;
-                switch (m.type) {
-                    case RT_MAT_LAMBERTIAN: {  // src/materials.rs:27-42
-                        dir = n + unit_vector(random_in_unit_sphere(rng));
-                        if (near_zero(dir)) dir = n;
-                        attenuation = texture_value(S, m, u, v);
-                        scattered = true;
-                        break;
-                    }
-                    case RT_MAT_METAL: {  // :53-66
-                        V3<T> reflected = reflect(unit_vector(ray.d), n);
-                        dir = reflected + m.param * random_in_unit_sphere(rng);
-                        attenuation = ld3(m.colour);
-                        metal = true;
-                        scattered = true;
-                        break;
-                    }
-                    case RT_MAT_DIELECTRIC: {  // :76-101
-                        T ratio = front ? (T)1.0 / m.param : m.param;
-                        V3<T> ud = unit_vector(ray.d);
-                        T cos_theta = fmin(dot(-ud, n), (T)1.0);
-                        T sin_theta = sqrt((T)1.0 - cos_theta * cos_theta);
-                        bool cannot_refract = ratio * sin_theta > (T)1.0;
-                        T random_fraction = rng.range((T)0.0, (T)1.0);
-                        dir = (cannot_refract || reflectance(cos_theta, ratio) > random_fraction) ? reflect(ud, n)
-                                                                                                 : refract(ud, n, ratio);
-                        scattered = true;
-                        break;
-                    }
-                    case RT_MAT_ISOTROPIC: {  // :146-153
-                        dir = random_in_unit_sphere(rng);
-                        attenuation = texture_value(S, m, u, v);
-                        scattered = true;
-                        break;
-                    }
-                    default: break;  // DiffuseLight::scatter -> None (:126-128)
-                }
-                // cast_ray(new_ray, .., bounces - 1) returns black once bounces hits 0 (src/hitting.rs:17-19).
-                V3<T> new_dir = unit_vector(dir);  // Ray::new normalises (src/math.rs:208-214)
-                if (metal) scattered = dot(new_dir, n) > (T)0.0;  // absorbed otherwise (src/materials.rs:61-65)
-                if (scattered && depth + 1 < max_bounces) {
-                    alive = true;
-                    nr.o = p;
-                    nr.d = new_dir;
-                    nr.time = ray.time;
-                    thr = coeff(thr, attenuation);
-                }
+            T t = 0, u = 0, v = 0;
+            V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
+            if (mf != RT_MISS) {
+                t = h.t[i]; u = h.u[i]; v = h.v[i];
+                n = mk(h.nx[i], h.ny[i], h.nz[i]);
             }
-            if (contributes) {
-                T* dst = sample_rgb + (uint64_t)pid * 3;
-                dst[0] += add.x; dst[1] += add.y; dst[2] += add.z;
-            }
+            alive = shade_path(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
         }
-        // Compaction: the survivors of input tile t are packed at the front of output tile t.
-        // One returning atomic per wave and tile on that tile's own counter (thousands of counters
-        // spread over the L2 channels; a single global counter saturates at ~90 atomics/us on
-        // MI355X).  A wave's items span one tile, rarely two; lanes are placed by ballot prefix.
-        unsigned long long todo = __ballot(alive);
-        while (todo) {
-            int leader = __ffsll((long long)todo) - 1;
-            uint32_t t_lead = __shfl(tile, leader);
-            unsigned long long same = __ballot(alive && tile == t_lead);
-            uint32_t start = 0;
-            if ((int)lane == leader) start = atomicAdd(&tile_counts_out[t_lead], (uint32_t)__popcll(same));
-            start = __shfl(start, leader);
-            if (alive && tile == t_lead) {
-                uint32_t o = t_lead * TILE + start + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                store_ray(qout, o, nr);
-                qout.tr[o] = thr.x; qout.tg[o] = thr.y; qout.tb[o] = thr.z;
-                qout.pid[o] = pid;
+        compact_store(alive, tile, nr, thr, pid, qout, tile_counts_out);
+    }
+}
+
+// extend + shade of one bounce in one kernel (the render path): the hit record never leaves the
+// registers, the ray is read once, and a bounce is one launch.  rt_trace keeps k_extend.
+template <typename T, int STACK, int MODE>
+__global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_bounce(DScene<T> S, DSmallScene small, DBatch B, DQueue<T> qin, DQueue<T> qout,
+                                                                    T* sample_rgb, uint32_t depth, uint32_t max_bounces,
+                                                                    const uint32_t* __restrict__ tile_offsets,
+                                                                    uint32_t* tile_counts_out, uint32_t n_tiles) {
+    __shared__ int32_t lds_stack[STACK * BLOCK];
+    constexpr bool LDS_SCENE = MODE == WALK_OWN_BOX_LDS;
+    __shared__ uint4 lds_scene[LDS_SCENE ? RT_LDS_SCENE_BYTES / 16 : 1];
+    Stack st{lds_stack + threadIdx.x, BLOCK};
+    DScene<T> W = S;  // the traversal's view of the scene (records in LDS for small worlds)
+    if (LDS_SCENE) stage_small_scene(W, small, lds_scene);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t total = tile_offsets[n_tiles];
+    for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < total; base += gridDim.x * BLOCK) {
+        const uint32_t d = base + lane;
+        const bool valid = d < total;
+        uint32_t tile = 0;
+        const uint32_t i = valid ? slot_of(tile_offsets, n_tiles, d, base, &tile) : 0u;
+        bool alive = false;
+        Ray<T> nr;
+        V3<T> thr;
+        uint32_t pid = 0;
+        if (valid) {
+            const Ray<T> ray = load_ray(qin, i);
+            pid = qin.pid[i];
+            const PathRef path{&B, pid};
+            T t = 0, u = 0, v = 0;
+            V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
+            uint32_t mf = RT_MISS;
+            Winner w;
+            if (closest_hit<T, MODE>(W, ray, (T)0.001, Lim<T>::inf(), st, path, depth, &t, &w)) {  // src/hitting.rs:20-21
+                const Surface<T> sf = make_surface(W, ray, t, w);
+                n = sf.normal; u = sf.u; v = sf.v;
+                mf = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
             }
-            todo &= ~same;
+            thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
+            alive = shade_path(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
         }
+        compact_store(alive, tile, nr, thr, pid, qout, tile_counts_out);
     }
 }
 
@@ -1076,14 +1253,33 @@ template <typename T>
 void Launch<T>::extend(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
                        uint32_t depth, const uint32_t* tile_offsets, uint32_t n_tiles, int stack, int grid_blocks,
                        hipStream_t st) {
-    if (small.blob && stack <= 16)
-        hipLaunchKernelGGL((k_extend<T, 16, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+    if (S.n_sweep > 0 && stack <= 16)
+        hipLaunchKernelGGL((k_extend<T, 16, WALK_SWEEP>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+    else if (S.n_sweep > 0)
+        hipLaunchKernelGGL((k_extend<T, 64, WALK_SWEEP>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+    else if (small.blob && stack <= 16)
+        hipLaunchKernelGGL((k_extend<T, 16, WALK_OWN_BOX_LDS>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (stack <= 16)
-        hipLaunchKernelGGL((k_extend<T, 16, false>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+        hipLaunchKernelGGL((k_extend<T, 16, WALK_NODE2>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (stack <= 32)
-        hipLaunchKernelGGL((k_extend<T, 32, false>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+        hipLaunchKernelGGL((k_extend<T, 32, WALK_NODE2>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else
-        hipLaunchKernelGGL((k_extend<T, 64, false>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+        hipLaunchKernelGGL((k_extend<T, 64, WALK_NODE2>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+}
+template <typename T>
+void Launch<T>::bounce(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> qin, DQueue<T> qout, T* sample_rgb,
+                       uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets, uint32_t* tile_counts_out,
+                       uint32_t n_tiles, int stack, int grid_blocks, hipStream_t st) {
+#define RT_BOUNCE(STACK, MODE)                                                                                            \
+    hipLaunchKernelGGL((k_bounce<T, STACK, MODE>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, qin, qout, sample_rgb, \
+                       depth, max_bounces, tile_offsets, tile_counts_out, n_tiles)
+    if (S.n_sweep > 0 && stack <= 16) RT_BOUNCE(16, WALK_SWEEP);
+    else if (S.n_sweep > 0) RT_BOUNCE(64, WALK_SWEEP);
+    else if (small.blob && stack <= 16) RT_BOUNCE(16, WALK_OWN_BOX_LDS);
+    else if (stack <= 16) RT_BOUNCE(16, WALK_NODE2);
+    else if (stack <= 32) RT_BOUNCE(32, WALK_NODE2);
+    else RT_BOUNCE(64, WALK_NODE2);
+#undef RT_BOUNCE
 }
 template <typename T>
 void Launch<T>::shade(const DScene<T>& S, const DBatch& B, DQueue<T> qin, DHits<T> h, DQueue<T> qout, T* sample_rgb,

@@ -111,7 +111,8 @@ struct DScene {
     const DImage* images;
     const uint8_t* texels;
     const int32_t* top_list;
-    int32_t n_top, tlas_root /* DNode2 super-root */, tlas_root_own /* DNode index */, pad_;
+    const int32_t* sweep;  // leaves (object indices) of a small world BVH in depth-first order; n_sweep == 0: walk the tree
+    int32_t n_top, tlas_root /* DNode2 super-root */, tlas_root_own /* DNode index */, n_sweep;
     DCamera<T> camera;
     DSky<T> sky;
 };
@@ -159,6 +160,10 @@ struct Launch {
     static void extend(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
                        uint32_t depth, const uint32_t* tile_offsets, uint32_t n_tiles, int stack, int grid_blocks,
                        hipStream_t st);
+    // extend + shade of one bounce in one launch (render path).
+    static void bounce(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> qin, DQueue<T> qout,
+                       T* sample_rgb, uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets,
+                       uint32_t* tile_counts_out, uint32_t n_tiles, int stack, int grid_blocks, hipStream_t st);
     static void shade(const DScene<T>& S, const DBatch& B, DQueue<T> qin, DHits<T> h, DQueue<T> qout, T* sample_rgb,
                       uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets, uint32_t* tile_counts_out,
                       uint32_t n_tiles, int grid_blocks, hipStream_t st);
