@@ -460,6 +460,7 @@ struct Engine : EngineBase {
     void build_sweep(const rt_scene_desc& d) {
         S.sweep = nullptr;
         S.n_sweep = 0;
+        S.lean = 0;
         if (d.tlas_root < 0) return;
         long limit = 12;
         if (const char* e = std::getenv("RT_SWEEP_MAX")) limit = std::strtol(e, nullptr, 10);
@@ -484,6 +485,11 @@ struct Engine : EngineBase {
             todo.push_back(nd.left);
         }
         if (order.empty()) return;
+        S.lean = 1;
+        for (uint64_t i = 0; i < d.n_objects; i++) {
+            const int32_t k = d.objects[i].kind;
+            if (k != RT_OBJ_RECTS && k != RT_OBJ_SPHERE && k != RT_OBJ_MOVING_SPHERE) S.lean = 0;
+        }
         sweep.upload(order);
         S.sweep = sweep.p;
         S.n_sweep = (int32_t)order.size();
@@ -642,9 +648,11 @@ struct Engine : EngineBase {
         HIP_CHECK(hipMemsetAsync(ray_total.p, 0, sizeof(unsigned long long), stream));
         size_t ev = 0;
         const bool timing = stats != nullptr;
-        // RT_FUSE=0 (environment) keeps the two-kernel bounce (extend, then shade) for A/B measurements.
+        // One fused launch per bounce pays off when the traversal is the lean sweep (no stack, no spills:
+        // cornell 30.5 -> 25.2 ms); with a divergent tree walk the shading half runs at the walk's low
+        // occupancy and loses (knight 95 -> 107 ms).  RT_FUSE=0 / 1 (environment) overrides for A/B runs.
         const char* fuse_env = std::getenv("RT_FUSE");
-        const bool fused = !(fuse_env && fuse_env[0] == '0');
+        const bool fused = fuse_env ? fuse_env[0] != '0' : (S.n_sweep > 0 && S.lean);
         std::vector<std::pair<size_t, int>> spans;  // (first event index, 0 = extend / 1 = shade)
         hipEvent_t ev_begin = event(ev++), ev_end = event(ev++);
         if (timing) HIP_CHECK(hipEventRecord(ev_begin, stream));

@@ -123,7 +123,7 @@ template <typename T> __device__ V3<T> random_in_unit_sphere(Rng<T>& rng) {  // 
         T py = rng.range((T)-1.0, (T)1.0);
         T pz = rng.range((T)-1.0, (T)1.0);
         V3<T> p = mk(px, py, pz);
-#ifdef RT_EXP_NOLOOP  // timing experiment only: wrong distribution
+#if defined(RT_EXP) && (RT_EXP & 1)  // timing experiment only: wrong distribution
         return p;
 #endif
         if (length_squared(p) <= (T)1.0) return p;
@@ -455,26 +455,35 @@ struct Winner {
 };
 
 // Hittable::hit of one non-medium object instance with bounds [min_dist, max_dist].
-template <typename T, bool UNIFORM>
+// FEAT: which object kinds a kernel variant compiles in besides rect lists (scenes made of walls,
+// boxes and spheres get a much smaller kernel that needs no scratch memory).
+enum { FEAT_SPHERES = 1, FEAT_FLAT = 2 /* Triangle / Plane objects */, FEAT_BLAS = 4, FEAT_MEDIA = 8, FEAT_ALL = 15 };
+
+template <typename T, bool UNIFORM, int FEAT>
 __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist,
                                   Stack st, int sp, T* t_out, int* prim_out) {
     const DObject ob = rec<UNIFORM>(&S.objects[oi]);
     Ray<T> r = world_ray;
     if (ob.xform >= 0) r = to_object_space(rec<UNIFORM>(&S.xforms[ob.xform]), world_ray);
-    switch (ob.kind) {
-        case RT_OBJ_SPHERE: {
+    if (ob.kind == RT_OBJ_RECTS) return rects_hit<T, UNIFORM>(S, r, ob.first, ob.count, min_dist, max_dist, t_out, prim_out);
+    if constexpr ((FEAT & FEAT_SPHERES) != 0) {
+        if (ob.kind == RT_OBJ_SPHERE) {
             const DSphere<T> s = rec<UNIFORM>(&S.spheres[ob.first]);
             *prim_out = ob.first;
             return distance_to_sphere(r, ld3(s.centre), s.radius, min_dist, max_dist, t_out);
         }
-        case RT_OBJ_MOVING_SPHERE: {
+        if (ob.kind == RT_OBJ_MOVING_SPHERE) {
             const DMovingSphere<T> s = rec<UNIFORM>(&S.moving_spheres[ob.first]);
             *prim_out = ob.first;
             return distance_to_sphere(r, moving_centre(s, r.time), s.radius, min_dist, max_dist, t_out);
         }
-        case RT_OBJ_RECTS: return rects_hit<T, UNIFORM>(S, r, ob.first, ob.count, min_dist, max_dist, t_out, prim_out);
-        case RT_OBJ_TRIANGLE: *prim_out = ob.first; return triangle_hit(rec<UNIFORM>(&S.triangles[ob.first]), r, min_dist, max_dist, t_out);
-        case RT_OBJ_PLANE: {  // src/objects.rs:599-606
+    }
+    if constexpr ((FEAT & FEAT_FLAT) != 0) {
+        if (ob.kind == RT_OBJ_TRIANGLE) {
+            *prim_out = ob.first;
+            return triangle_hit(rec<UNIFORM>(&S.triangles[ob.first]), r, min_dist, max_dist, t_out);
+        }
+        if (ob.kind == RT_OBJ_PLANE) {  // src/objects.rs:599-606
             const DPlane<T> p = rec<UNIFORM>(&S.planes[ob.first]);
             V3<T> s;
             if (!line_plane_collision(r.o, r.d, ld3(p.point), ld3(p.vec1), ld3(p.vec2), &s)) return false;
@@ -483,12 +492,13 @@ __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& worl
             *prim_out = ob.first;
             return true;
         }
-        case RT_OBJ_BLAS: return blas_hit(S, r, ob.first, min_dist, max_dist, st, sp, t_out, prim_out);
-        default: return false;
     }
+    if constexpr ((FEAT & FEAT_BLAS) != 0) {
+        if (ob.kind == RT_OBJ_BLAS) return blas_hit(S, r, ob.first, min_dist, max_dist, st, sp, t_out, prim_out);
+    }
+    return false;
 }
 
-// Hittable::hit of any object instance, constant media included (src/objects.rs:404-448).
 // The stream of a path's draws is named by (pixel, sample); both come from the path id by an
 // integer division, which only the rare constant-medium draw needs: computed there.
 struct PathRef {
@@ -496,11 +506,22 @@ struct PathRef {
     uint32_t pid;
 };
 
-template <typename T, bool UNIFORM>
+// ln(xi) of the constant-medium draw (src/objects.rs:428-429).  Out of line: f64 log and the stream
+// set-up are rare and would otherwise keep their constants live across the whole traversal loop.
+template <typename T>
+__device__ __noinline__ T medium_log_draw(PathRef path, uint32_t rng_key, uint32_t depth) {
+    uint32_t pixel, sample;
+    path_ids(*path.batch, path.pid, &pixel, &sample);
+    Rng<T> rng(path.batch->seed, DOMAIN_MEDIUM | rng_key, pixel, sample, depth);
+    return log(rng.next());
+}
+
+template <typename T, bool UNIFORM, int FEAT>
 __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist, Stack st,
                            int sp, PathRef path, uint32_t depth, T* t_out, int* prim_out) {
     const DObject ob = rec<UNIFORM>(&S.objects[oi]);
-    if (ob.kind != RT_OBJ_MEDIUM) return simple_object_hit<T, UNIFORM>(S, oi, world_ray, min_dist, max_dist, st, sp, t_out, prim_out);
+    if ((FEAT & FEAT_MEDIA) == 0 || ob.kind != RT_OBJ_MEDIUM)
+        return simple_object_hit<T, UNIFORM, FEAT>(S, oi, world_ray, min_dist, max_dist, st, sp, t_out, prim_out);
     const DMedium<T> md = rec<UNIFORM>(&S.media[ob.first]);
     Ray<T> r = world_ray;
     if (ob.xform >= 0) r = to_object_space(rec<UNIFORM>(&S.xforms[ob.xform]), world_ray);
@@ -508,18 +529,15 @@ __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, 
     T t1, t2;
     int ignore;
     // (the second query runs only in the lanes whose first one hit, so it is not wave-uniform)
-    if (!simple_object_hit<T, UNIFORM>(S, md.boundary_object, r, -inf, inf, st, sp, &t1, &ignore)) return false;
-    if (!simple_object_hit<T, UNIFORM>(S, md.boundary_object, r, t1 + (T)0.0001, inf, st, sp, &t2, &ignore)) return false;
+    if (!simple_object_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, -inf, inf, st, sp, &t1, &ignore)) return false;
+    if (!simple_object_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, t1 + (T)0.0001, inf, st, sp, &t2, &ignore)) return false;
     if (t1 < min_dist) t1 = min_dist;
     if (t2 > max_dist) t2 = max_dist;
     if (t1 >= t2) return false;
     if (t1 < (T)0.0) t1 = (T)0.0;
     T ray_length = length(r.d);
     T distance_inside_boundary = (t2 - t1) * ray_length;
-    uint32_t pixel, sample;
-    path_ids(*path.batch, path.pid, &pixel, &sample);
-    Rng<T> rng(path.batch->seed, DOMAIN_MEDIUM | md.rng_key, pixel, sample, depth);
-    T hit_distance = md.neg_inv_density * log(rng.next());
+    T hit_distance = md.neg_inv_density * medium_log_draw<T>(path, md.rng_key, depth);
     if (hit_distance > distance_inside_boundary) return false;
     *t_out = t1 + hit_distance / ray_length;
     *prim_out = ob.first;
@@ -528,12 +546,15 @@ __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, 
 
 // world.hit(ray, min, max): the top-level Vec (src/hitting.rs:188-194 -> :88-104) over the
 // world BVH and the unbounded objects; inside the BVH, BVHNode::hit (:211-229).
-enum { WALK_NODE2 = 0, WALK_OWN_BOX_LDS = 1, WALK_SWEEP = 2 };
+enum { WALK_NODE2 = 0, WALK_OWN_BOX_LDS = 1, WALK_SWEEP = 2, WALK_SWEEP_LEAN = 3 /* rect lists and spheres only */ };
+template <int MODE> struct WalkFeat { static constexpr int value = MODE == WALK_SWEEP_LEAN ? FEAT_SPHERES : FEAT_ALL; };
 
 template <typename T, int MODE>
 __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T max_dist, Stack st, PathRef path,
                             uint32_t depth, T* t_out, Winner* w_out) {
-    constexpr bool UNI = MODE == WALK_SWEEP;  // the top-level list is walked in step by all lanes
+    constexpr bool SWEEP = MODE == WALK_SWEEP || MODE == WALK_SWEEP_LEAN;
+    constexpr bool UNI = SWEEP;  // the top-level list is walked in step by all lanes
+    constexpr int FEAT = WalkFeat<MODE>::value;
     bool have = false;
     T best_t = 0;
     Winner best{-1, -1};
@@ -543,9 +564,9 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
         T t = 0;
         Winner w{-1, -1};
         if (entry != RT_TOP_BVH) {
-            found = object_hit<T, UNI>(S, entry, ray, min_dist, max_dist, st, 0, path, depth, &t, &w.prim);
+            found = object_hit<T, UNI, FEAT>(S, entry, ray, min_dist, max_dist, st, 0, path, depth, &t, &w.prim);
             w.obj = entry;
-        } else if (MODE == WALK_SWEEP) {
+        } else if (SWEEP) {
             // Worlds of a few objects: no tree walk at all.  The leaves of the reference BVH are visited
             // in its depth-first order (left child first) with the same shrinking bound and the same
             // "t <= bound: the later leaf wins" rule, so the winner is the one BVHNode::hit returns
@@ -557,6 +578,12 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
             for (int k = 0; k < S.n_sweep; k++) {
                 const int oi = rec<true>(&S.sweep[k]);
                 const DObject ob = rec<true>(&S.objects[oi]);
+#if defined(RT_EXP) && (RT_EXP & 4)  // timing experiment only: no transformed objects
+                if (ob.xform >= 0) continue;
+#endif
+#if defined(RT_EXP) && (RT_EXP & 8)  // timing experiment only: transformed objects only
+                if (ob.xform < 0 && k > 0) continue;
+#endif
                 T th = 0;
                 int prim = -1;
                 bool hit;
@@ -568,7 +595,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                         hit = rects_hit_uniform(S, ray, ob.first, ob.count, min_dist, bound, &th, &prim);
                     }
                 } else {
-                    hit = object_hit<T, true>(S, oi, ray, min_dist, bound, st, 0, path, depth, &th, &prim);
+                    hit = object_hit<T, true, FEAT>(S, oi, ray, min_dist, bound, st, 0, path, depth, &th, &prim);
                 }
                 bound = hit ? th : bound;
                 w.obj = hit ? oi : w.obj;
@@ -590,7 +617,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                     int oi = -1 - left;
                     T th;
                     int prim;
-                    if (object_hit<T, false>(S, oi, ray, min_dist, bound, st, sp, path, depth, &th, &prim)) {
+                    if (object_hit<T, false, FEAT>(S, oi, ray, min_dist, bound, st, sp, path, depth, &th, &prim)) {
                         bound = th;
                         w.obj = oi;
                         w.prim = prim;
@@ -621,7 +648,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                     const int oi = -1 - next;
                     T th;
                     int prim;
-                    if (object_hit<T, false>(S, oi, ray, min_dist, bound, st, sp, path, depth, &th, &prim)) {
+                    if (object_hit<T, false, FEAT>(S, oi, ray, min_dist, bound, st, sp, path, depth, &th, &prim)) {
                         bound = th;
                         bound32 = round_up(th);
                         w.obj = oi;
@@ -657,12 +684,18 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
 }
 
 template <typename T>
-__device__ __forceinline__ void get_sphere_uv(V3<T> p, T* u, T* v) {  // src/math.rs:288-294
+__device__ __noinline__ void get_sphere_uv(V3<T> p, T* u, T* v) {  // src/math.rs:288-294
     const T PI = (T)3.14159265358979323846264338327950288;
     T theta = acos(-p.y);
     T phi = atan2(-p.z, p.x) + PI;
     *u = phi / ((T)2.0 * PI);
     *v = theta / PI;
+}
+
+template <typename T>
+__device__ __noinline__ T plane_uv(T x, T repeat) {  // src/objects.rs:609-616 (f64 fmod is a long loop: out of line)
+    T u = fmod(x, repeat) / repeat;
+    return u < (T)0.0 ? (T)1.0 + u : u;
 }
 
 template <typename T>
@@ -676,7 +709,7 @@ struct Surface {  // HitRecord, src/hitting.rs:33-41
 // Rebuilds the HitRecord of the winning primitive: outward normal and (u,v) of the
 // primitive, HitRecord::new's face logic (src/hitting.rs:57-79), then the normal rotated
 // back to world space as the Rotate*::hit wrappers do (src/transforms.rs:119-121 etc.).
-template <typename T>
+template <typename T, int FEAT>
 __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, T t, Winner w) {
     const DObject ob = S.objects[w.obj];
     Ray<T> r = world_ray;
@@ -687,72 +720,59 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
     sf.v = 0;
     sf.sub = 0;
     bool medium = false, unit_already = false;
-    switch (ob.kind) {
-        case RT_OBJ_SPHERE: {
-            const DSphere<T>& s = S.spheres[w.prim];
-            outward = (r.at(t) - ld3(s.centre)) / s.radius;
-            get_sphere_uv(outward, &sf.u, &sf.v);
-            sf.material = s.material;
-            sf.owner = s.owner;
-            break;
-        }
-        case RT_OBJ_MOVING_SPHERE: {
-            const DMovingSphere<T>& s = S.moving_spheres[w.prim];
-            outward = (r.at(t) - moving_centre(s, r.time)) / s.radius;
-            get_sphere_uv(outward, &sf.u, &sf.v);
-            sf.material = s.material;
-            sf.owner = s.owner;
-            break;
-        }
-        case RT_OBJ_RECTS: {
-            const DRect<T>& q = S.rects[w.prim];
-            int axis = q.axis;
-            int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
-            T a = comp(r.o, ia) + t * comp(r.d, ia);
-            T b = comp(r.o, ib) + t * comp(r.d, ib);
-            sf.u = (a - q.a0) / (q.a1 - q.a0);
-            sf.v = (b - q.b0) / (q.b1 - q.b0);
-            T s = q.facing_positive ? (T)1.0 : (T)-1.0;
-            outward = mk(axis == 0 ? s : (T)0.0, axis == 1 ? s : (T)0.0, axis == 2 ? s : (T)0.0);
-            unit_already = true;  // (+-1, 0, 0) / sqrt(1) is itself, bit for bit: skip HitRecord::new's unit_vector
-            sf.material = q.material;
-            sf.owner = q.owner;
-            sf.sub = q.sub;
-            break;
-        }
-        case RT_OBJ_TRIANGLE:
-        case RT_OBJ_BLAS: {
-            const DTriangle<T>& tr = S.triangles[w.prim];
-            V3<T> s;
-            line_plane_collision(r.o, r.d, ld3(tr.point), ld3(tr.vec1), ld3(tr.vec2), &s);
-            sf.u = s.z;  // (solution[2], solution[1]), src/objects.rs:552
-            sf.v = s.y;
-            outward = ld3(tr.normal);
-            sf.material = tr.material;
-            sf.owner = tr.owner;
-            sf.sub = tr.sub;
-            break;
-        }
-        case RT_OBJ_PLANE: {  // src/objects.rs:607-617
-            const DPlane<T>& p = S.planes[w.prim];
-            V3<T> s;
-            line_plane_collision(r.o, r.d, ld3(p.point), ld3(p.vec1), ld3(p.vec2), &s);
-            T u = fmod(s.y, p.uv_repeat) / p.uv_repeat;
-            T v = fmod(-s.z, p.uv_repeat) / p.uv_repeat;
-            sf.u = u < (T)0.0 ? (T)1.0 + u : u;
-            sf.v = v < (T)0.0 ? (T)1.0 + v : v;
-            outward = ld3(p.normal);
-            sf.material = p.material;
-            sf.owner = p.owner;
-            break;
-        }
-        default: {  // RT_OBJ_MEDIUM: normal (1,0,0), front_face true, uv 0 (src/objects.rs:431-439)
-            const DMedium<T>& md = S.media[w.prim];
-            sf.material = md.material;
-            sf.owner = md.owner;
-            medium = true;
-            break;
-        }
+    sf.material = 0;
+    sf.owner = -1;
+    const int kind = ob.kind;
+    if (kind == RT_OBJ_RECTS) {
+        const DRect<T>& q = S.rects[w.prim];
+        int axis = q.axis;
+        int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
+        T a = comp(r.o, ia) + t * comp(r.d, ia);
+        T b = comp(r.o, ib) + t * comp(r.d, ib);
+        sf.u = (a - q.a0) / (q.a1 - q.a0);
+        sf.v = (b - q.b0) / (q.b1 - q.b0);
+        T s = q.facing_positive ? (T)1.0 : (T)-1.0;
+        outward = mk(axis == 0 ? s : (T)0.0, axis == 1 ? s : (T)0.0, axis == 2 ? s : (T)0.0);
+        unit_already = true;  // (+-1, 0, 0) / sqrt(1) is itself, bit for bit: skip HitRecord::new's unit_vector
+        sf.material = q.material;
+        sf.owner = q.owner;
+        sf.sub = q.sub;
+    } else if ((FEAT & FEAT_SPHERES) != 0 && kind == RT_OBJ_SPHERE) {
+        const DSphere<T>& s = S.spheres[w.prim];
+        outward = (r.at(t) - ld3(s.centre)) / s.radius;
+        get_sphere_uv(outward, &sf.u, &sf.v);
+        sf.material = s.material;
+        sf.owner = s.owner;
+    } else if ((FEAT & FEAT_SPHERES) != 0 && kind == RT_OBJ_MOVING_SPHERE) {
+        const DMovingSphere<T>& s = S.moving_spheres[w.prim];
+        outward = (r.at(t) - moving_centre(s, r.time)) / s.radius;
+        get_sphere_uv(outward, &sf.u, &sf.v);
+        sf.material = s.material;
+        sf.owner = s.owner;
+    } else if ((FEAT & (FEAT_FLAT | FEAT_BLAS)) != 0 && (kind == RT_OBJ_TRIANGLE || kind == RT_OBJ_BLAS)) {
+        const DTriangle<T>& tr = S.triangles[w.prim];
+        V3<T> s;
+        line_plane_collision(r.o, r.d, ld3(tr.point), ld3(tr.vec1), ld3(tr.vec2), &s);
+        sf.u = s.z;  // (solution[2], solution[1]), src/objects.rs:552
+        sf.v = s.y;
+        outward = ld3(tr.normal);
+        sf.material = tr.material;
+        sf.owner = tr.owner;
+        sf.sub = tr.sub;
+    } else if ((FEAT & FEAT_FLAT) != 0 && kind == RT_OBJ_PLANE) {  // src/objects.rs:607-617
+        const DPlane<T>& p = S.planes[w.prim];
+        V3<T> s;
+        line_plane_collision(r.o, r.d, ld3(p.point), ld3(p.vec1), ld3(p.vec2), &s);
+        sf.u = plane_uv(s.y, p.uv_repeat);
+        sf.v = plane_uv(-s.z, p.uv_repeat);
+        outward = ld3(p.normal);
+        sf.material = p.material;
+        sf.owner = p.owner;
+    } else if ((FEAT & FEAT_MEDIA) != 0 && kind == RT_OBJ_MEDIUM) {  // normal (1,0,0), front_face true, uv 0 (src/objects.rs:431-439)
+        const DMedium<T>& md = S.media[w.prim];
+        sf.material = md.material;
+        sf.owner = md.owner;
+        medium = true;
     }
     if (medium) {
         sf.front_face = true;
@@ -913,7 +933,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
         T t;
         Winner w;
         if (closest_hit<T, MODE>(S, r, min_dist, max_dist, st, path, depth, &t, &w)) {
-            Surface<T> sf = make_surface(S, r, t, w);
+            Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(S, r, t, w);
             h.t[i] = t;
             h.nx[i] = sf.normal.x; h.ny[i] = sf.normal.y; h.nz[i] = sf.normal.z;
             h.u[i] = sf.u; h.v[i] = sf.v;
@@ -947,10 +967,24 @@ __device__ __forceinline__ V3<T> texture_value(const DScene<T>& S, const DMateri
 }
 
 template <typename T>
-__device__ __forceinline__ T reflectance(T cosine, T ref_idx) {  // src/materials.rs:107-111 (1.1 as written)
+__device__ __noinline__ T reflectance(T cosine, T ref_idx) {  // src/materials.rs:107-111 (1.1 as written)
     T r0 = ((T)1.1 - ref_idx) / ((T)1.0 + ref_idx);
     r0 = r0 * r0;
     return r0 + ((T)1.0 - r0) * pow((T)1.0 - cosine, (T)5.0);
+}
+
+// Checkered::{emitted, scatter} (src/materials.rs:166-183) pick a part by the sign of
+// sin(k f u) sin(k f v), f = PI in scatter and 1 in emitted, possibly through nested checkers.
+// Out of line: f64 sin carries a large argument reduction that would otherwise sit in every kernel.
+template <typename T>
+__device__ __noinline__ int resolve_checkered(const DScene<T>& S, int mi, T u, T v, T f) {
+    DMaterial<T> m = S.materials[mi];
+    while (m.type == RT_MAT_CHECKERED) {
+        T sines = sin(m.param * f * u) * sin(m.param * f * v);
+        mi = sines < (T)0.0 ? m.odd : m.even;
+        m = S.materials[mi];
+    }
+    return mi;
 }
 
 // One bounce of cast_ray for one path (src/hitting.rs:11-31) after its closest-hit query: adds what
@@ -983,9 +1017,8 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
         {
             int me = mi;
             DMaterial<T> m = S.materials[me];
-            while (m.type == RT_MAT_CHECKERED) {
-                T sines = sin(m.param * u) * sin(m.param * v);
-                me = sines < (T)0.0 ? m.odd : m.even;
+            if (m.type == RT_MAT_CHECKERED) {
+                me = resolve_checkered(S, me, u, v, (T)1.0);
                 m = S.materials[me];
             }
             if (m.type == RT_MAT_DIFFUSE_LIGHT && front) {  // src/materials.rs:129-136
@@ -995,9 +1028,8 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
         }
         // scatter(): Checkered picks with sin(k PI u) sin(k PI v) (src/materials.rs:166-174)
         DMaterial<T> m = S.materials[mi];
-        while (m.type == RT_MAT_CHECKERED) {
-            T sines = sin(m.param * PI * u) * sin(m.param * PI * v);
-            mi = sines < (T)0.0 ? m.odd : m.even;
+        if (m.type == RT_MAT_CHECKERED) {
+            mi = resolve_checkered(S, mi, u, v, PI);
             m = S.materials[mi];
         }
         uint32_t pixel, sample;
@@ -1008,7 +1040,11 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
         bool scattered = false, metal = false;
         switch (m.type) {
             case RT_MAT_LAMBERTIAN: {  // src/materials.rs:27-42
+#if defined(RT_EXP) && (RT_EXP & 2)  // timing experiment only: no random numbers
+                dir = n + mk((T)0.1, (T)0.2, (T)0.3) * ray.d.x;
+#else
                 dir = n + unit_vector(random_in_unit_sphere(rng));
+#endif
                 if (near_zero(dir)) dir = n;
                 attenuation = texture_value(S, m, u, v);
                 scattered = true;
@@ -1154,9 +1190,14 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_bounce(DScene<T> S, 
             uint32_t mf = RT_MISS;
             Winner w;
             if (closest_hit<T, MODE>(W, ray, (T)0.001, Lim<T>::inf(), st, path, depth, &t, &w)) {  // src/hitting.rs:20-21
-                const Surface<T> sf = make_surface(W, ray, t, w);
+#if defined(RT_EXP) && (RT_EXP & 16)  // timing experiment only: no surface reconstruction
+                n = mk((T)0.0, (T)1.0, (T)0.0);
+                mf = (uint32_t)W.rects[w.prim].material | 0x80000000u;
+#else
+                const Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(W, ray, t, w);
                 n = sf.normal; u = sf.u; v = sf.v;
                 mf = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
+#endif
             }
             thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
             alive = shade_path(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
@@ -1253,7 +1294,9 @@ template <typename T>
 void Launch<T>::extend(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
                        uint32_t depth, const uint32_t* tile_offsets, uint32_t n_tiles, int stack, int grid_blocks,
                        hipStream_t st) {
-    if (S.n_sweep > 0 && stack <= 16)
+    if (S.n_sweep > 0 && S.lean)
+        hipLaunchKernelGGL((k_extend<T, 1, WALK_SWEEP_LEAN>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+    else if (S.n_sweep > 0 && stack <= 16)
         hipLaunchKernelGGL((k_extend<T, 16, WALK_SWEEP>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (S.n_sweep > 0)
         hipLaunchKernelGGL((k_extend<T, 64, WALK_SWEEP>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
@@ -1273,7 +1316,8 @@ void Launch<T>::bounce(const DScene<T>& S, const DSmallScene& small, const DBatc
 #define RT_BOUNCE(STACK, MODE)                                                                                            \
     hipLaunchKernelGGL((k_bounce<T, STACK, MODE>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, qin, qout, sample_rgb, \
                        depth, max_bounces, tile_offsets, tile_counts_out, n_tiles)
-    if (S.n_sweep > 0 && stack <= 16) RT_BOUNCE(16, WALK_SWEEP);
+    if (S.n_sweep > 0 && S.lean) RT_BOUNCE(1, WALK_SWEEP_LEAN);
+    else if (S.n_sweep > 0 && stack <= 16) RT_BOUNCE(16, WALK_SWEEP);
     else if (S.n_sweep > 0) RT_BOUNCE(64, WALK_SWEEP);
     else if (small.blob && stack <= 16) RT_BOUNCE(16, WALK_OWN_BOX_LDS);
     else if (stack <= 16) RT_BOUNCE(16, WALK_NODE2);

@@ -113,6 +113,7 @@ struct DScene {
     const int32_t* top_list;
     const int32_t* sweep;  // leaves (object indices) of a small world BVH in depth-first order; n_sweep == 0: walk the tree
     int32_t n_top, tlas_root /* DNode2 super-root */, tlas_root_own /* DNode index */, n_sweep;
+    int32_t lean, pad_[3];  // lean: every object is a rect list or a sphere (no meshes, media, planes, lone triangles)
     DCamera<T> camera;
     DSky<T> sky;
 };
