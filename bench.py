@@ -59,7 +59,7 @@ def extend_flops_per_ray(scene_name: str) -> float:
     return st["nodes_per_ray"] * 21 + st["prims_per_ray"] * PRIM_FLOPS[PRIM_KIND.get(scene_name, "rect")] + st["xforms_per_ray"] * 40
 
 
-def measured_traffic(scene_name: str, prec: str):
+def measured_traffic(scene_name: str, prec: str, kernel: str = None):
     """HBM bytes per k_extend launch from the PMC passes committed under profiles/ (separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950); None when no pass exists for this scene."""
@@ -68,7 +68,7 @@ def measured_traffic(scene_name: str, prec: str):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
         with open(path) as f:
             t = json.load(f).get(scene_name)
-        if t and t.get("precision") == prec:
+        if t and t.get("precision") == prec and (kernel is None or t.get("kernel") == kernel):
             return t["traffic_bytes_per_launch"]
     return None
 
@@ -206,7 +206,20 @@ def main() -> None:
     # LDS / L2 / Infinity Cache and are reported separately as `touched`.
     rays_per_launch = rays / max(n_extend, 1.0)
     ms_per_launch = ms_extend / max(n_extend, 1.0)
-    bytes_per_launch = (r["ray"] + r["hit"]) * rays_per_launch + scene_bytes
+    # Small worlds of rects and spheres run extend + shade as ONE kernel per bounce (k_bounce; the
+    # library reports its time as ms_extend and no shade launches): it reads a path's queue entry
+    # (ray 56 B + throughput 24 B + path id 4 B in f64) and writes one for every survivor; the
+    # survivors of all launches are the rays of the later launches = rays - paths.
+    fused = sum(s.shade_launches for s in stats) == 0 and n_extend > 0
+    kernel = "k_bounce" if fused else "k_extend"
+    path_bytes = 84 if args.precision == "f64" else 44
+    paths = float(sum(s.paths for s in stats))
+    if fused:
+        bytes_per_launch = (path_bytes * rays + path_bytes * (rays - paths)) / max(n_extend, 1.0) + scene_bytes
+        bytes_per_ray = path_bytes * (2.0 - paths / max(rays, 1.0))
+    else:
+        bytes_per_launch = (r["ray"] + r["hit"]) * rays_per_launch + scene_bytes
+        bytes_per_ray = r["ray"] + r["hit"]
     achieved_gbs = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
     touched_bpr = extend_bytes_per_ray(args.scene, args.precision)
     touched_gbs = touched_bpr * rays / (ms_extend * 1e-3) / 1e9 if ms_extend > 0 else 0.0
@@ -232,15 +245,16 @@ def main() -> None:
             "wall_clock_per_image_s": dt / args.steps, "seed": args.seed,
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_extend", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(args.scene, args.precision),
-            "bytes_per_launch": bytes_per_launch, "bytes_per_ray": r["ray"] + r["hit"], "scene_bytes": scene_bytes,
+            "bound": "hbm", "kernel": kernel, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(args.scene, args.precision, kernel),
+            "bytes_per_launch": bytes_per_launch, "bytes_per_ray": bytes_per_ray, "scene_bytes": scene_bytes,
             "launches": n_extend, "avg_launch_ms": ms_per_launch, "rays_per_launch": rays_per_launch,
             "touched": {"bytes_per_ray": touched_bpr, "achieved_GBps": touched_gbs,
                         "note": "all records the reference traversal touches per ray (SURVEY 8d sum, f64 sizes); served mostly by LDS / L2 / Infinity Cache"},
-            "note": "k_extend is bound by dependent-fetch latency and f64 VALU, not by HBM bandwidth (see roofline_valu and DESIGN.md)",
+            "note": kernel + " is bound by f64 VALU issue (and, on meshes, dependent-fetch latency), not by HBM bandwidth "
+                    "(see roofline_valu, profiles/ and DESIGN.md)",
         },
-        "roofline_valu": {"kernel": "k_extend", "achieved": flops, "peak": valu_peak, "unit": "TFLOP/s", "frac": flops / valu_peak},
+        "roofline_valu": {"kernel": kernel, "achieved": flops, "peak": valu_peak, "unit": "TFLOP/s", "frac": flops / valu_peak},
         "stage_ms_per_step": {"extend": ms_extend / args.steps, "shade": float(t[4]) / args.steps, "gpu_total": float(t[5]) / args.steps},
     }
     if world == 1 and not args.no_cpu_baseline:
