@@ -257,14 +257,17 @@ struct Engine : EngineBase {
         // Traversal layout: the reference-style tree (rt_node: every node holds its own f64 box) is
         // re-laid as DNode2 records that hold the boxes of both children (see rt_device.h).
         std::vector<int32_t> root2(d.n_nodes, -1);  // rt_node root index -> DNode2 super-root index
+        LeafRanks ranks;
+        ranks.object.assign(d.n_objects, 0);
+        ranks.triangle.assign(d.n_triangles, 0);
         {
             std::vector<rtd::DNode2> v;
             v.reserve(d.n_nodes / 2 + 8);
             const float pad = box_pad(d);
-            if (d.tlas_root >= 0) root2[d.tlas_root] = build_nodes2(d, d.tlas_root, pad, v);
+            if (d.tlas_root >= 0) root2[d.tlas_root] = build_nodes2(d, d.tlas_root, pad, v, ranks);
             for (uint64_t i = 0; i < d.n_objects; i++)
                 if (d.objects[i].kind == RT_OBJ_BLAS && root2[d.objects[i].first] < 0)
-                    root2[d.objects[i].first] = build_nodes2(d, d.objects[i].first, pad, v);
+                    root2[d.objects[i].first] = build_nodes2(d, d.objects[i].first, pad, v, ranks);
             nodes2.upload(v);
             n_nodes2 = v.size();
         }
@@ -272,7 +275,15 @@ struct Engine : EngineBase {
             std::vector<rtd::DObject> v(d.n_objects);
             for (size_t i = 0; i < v.size(); i++) {
                 const rt_object& o = d.objects[i];
-                v[i] = rtd::DObject{o.kind, o.xform, o.kind == RT_OBJ_BLAS ? root2[o.first] : o.first, o.count, o.world_index, {0, 0, 0}};
+                int32_t block6 = 0;
+                if (o.kind == RT_OBJ_RECTS && o.count == 6) {
+                    static const int32_t axes[6] = {2, 2, 1, 1, 0, 0};
+                    block6 = 1;
+                    for (int k = 0; k < 6; k++)
+                        if (d.rects[o.first + k].axis != axes[k]) block6 = 0;
+                }
+                v[i] = rtd::DObject{o.kind, o.xform, o.kind == RT_OBJ_BLAS ? root2[o.first] : o.first, o.count, o.world_index,
+                                    ranks.object[i], block6, 0};
             }
             objects.upload(v);
         }
@@ -321,7 +332,7 @@ struct Engine : EngineBase {
             for (size_t i = 0; i < v.size(); i++) {
                 const rt_triangle& t = d.triangles[i];
                 cvt3(v[i].point, t.point); cvt3(v[i].vec1, t.vec1); cvt3(v[i].vec2, t.vec2); cvt3(v[i].normal, t.normal);
-                v[i].material = t.material; v[i].owner = t.owner; v[i].sub = t.sub; v[i].pad = 0;
+                v[i].material = t.material; v[i].owner = t.owner; v[i].sub = t.sub; v[i].dfs_rank = ranks.triangle[i];
             }
             triangles.upload(v);
         }
@@ -378,6 +389,12 @@ struct Engine : EngineBase {
         S.sky.gradient = d.sky.gradient;
         cvt3(S.sky.colour, d.sky.colour); cvt3(S.sky.unit_dir, d.sky.unit_dir);
         cvt3(S.sky.colour0, d.sky.colour0); cvt3(S.sky.colour1, d.sky.colour1);
+        // RT_ORDERED=0 (environment) walks trees in the reference's fixed left-first order (A/B runs).
+        const char* ordered_env = std::getenv("RT_ORDERED");
+        S.ordered = !(ordered_env && ordered_env[0] == '0');
+        S.needs_uv = 0;
+        for (uint64_t i = 0; i < d.n_materials; i++)
+            if (d.materials[i].image >= 0 || d.materials[i].type == RT_MAT_CHECKERED) S.needs_uv = 1;
         stack_depth = d.stack_depth;
         build_small_scene(d);
         build_sweep(d);
@@ -406,8 +423,16 @@ struct Engine : EngineBase {
     }
 
     // One child slot of a DNode2 from reference node `idx`; returns the child reference.
+    // Depth-first (left child first) rank of every leaf payload: the reference's BVHNode::hit lets the
+    // later leaf win an exact tie (src/hitting.rs:211-229); the kernels walk the nearer child first and
+    // use these ranks to give the same answer.
+    struct LeafRanks {
+        std::vector<int32_t> object, triangle;
+        int32_t next = 0;
+    };
+
     static int32_t node2_child(const rt_scene_desc& d, int32_t idx, float pad, std::vector<rtd::DNode2>& out, float* lo,
-                               float* hi) {
+                               float* hi, LeafRanks& ranks) {
         const rt_node& nd = d.nodes[idx];
         bool well_formed = true, flat = false;
         for (int k = 0; k < 3; k++) {
@@ -425,7 +450,11 @@ struct Engine : EngineBase {
                 hi[k] = INFINITY;
             }
         }
-        if (nd.left < 0) return nd.left;  // leaf: payload reference, box = its (padded) bounds
+        if (nd.left < 0) {  // leaf: payload reference, box = its (padded) bounds
+            auto& table = nd.right == RT_LEAF_TRIANGLE ? ranks.triangle : ranks.object;
+            table[(size_t)(-1 - nd.left)] = ranks.next++;
+            return nd.left;
+        }
         // Interior node.  AABB::intersects rejects when max_dist <= min_dist (src/hitting.rs:262): a box
         // of zero thickness on an axis yields t0 == t1 there and is culled for every ray, so the whole
         // subtree is invisible in the reference - dropped here for the same result.
@@ -434,19 +463,19 @@ struct Engine : EngineBase {
         out.emplace_back();
         rtd::DNode2 n;
         std::memset(&n, 0, sizeof(n));
-        n.child[0] = node2_child(d, nd.left, pad, out, n.lo[0], n.hi[0]);
-        n.child[1] = node2_child(d, nd.right, pad, out, n.lo[1], n.hi[1]);
+        n.child[0] = node2_child(d, nd.left, pad, out, n.lo[0], n.hi[0], ranks);
+        n.child[1] = node2_child(d, nd.right, pad, out, n.lo[1], n.hi[1], ranks);
         out[(size_t)me] = n;
         return me;
     }
 
     // DNode2 super-root for the reference BVH rooted at `root`: child 0 = that root, child 1 empty.
-    static int32_t build_nodes2(const rt_scene_desc& d, int32_t root, float pad, std::vector<rtd::DNode2>& out) {
+    static int32_t build_nodes2(const rt_scene_desc& d, int32_t root, float pad, std::vector<rtd::DNode2>& out, LeafRanks& ranks) {
         int32_t me = (int32_t)out.size();
         out.emplace_back();
         rtd::DNode2 n;
         std::memset(&n, 0, sizeof(n));
-        n.child[0] = node2_child(d, root, pad, out, n.lo[0], n.hi[0]);
+        n.child[0] = node2_child(d, root, pad, out, n.lo[0], n.hi[0], ranks);
         n.child[1] = rtd::RT_EMPTY;
         out[(size_t)me] = n;
         return me;

@@ -285,6 +285,26 @@ __device__ __forceinline__ bool rects_hit_uniform(const DScene<T>& S, const Ray<
     return have;
 }
 
+// A Block (src/objects.rs:149-168) is always the rect list z, z, y, y, x, x: with the axes known at
+// compile time the six tests are straight-line code (no per-lane component selects, no branches).
+// Same list rule as rects_hit: every side sees the same [min,max], strict < keeps the first.
+template <typename T>
+__device__ __forceinline__ bool block6_hit(const DScene<T>& S, const Ray<T>& r, int first, T min_dist, T max_dist, T* t_out,
+                                           int* prim_out) {
+    bool have = false;
+    T bt = 0;
+    int bi = -1;
+    rect_axis_test<T, 2>(S.rects[first + 0], first + 0, r, min_dist, max_dist, have, bt, bi);
+    rect_axis_test<T, 2>(S.rects[first + 1], first + 1, r, min_dist, max_dist, have, bt, bi);
+    rect_axis_test<T, 1>(S.rects[first + 2], first + 2, r, min_dist, max_dist, have, bt, bi);
+    rect_axis_test<T, 1>(S.rects[first + 3], first + 3, r, min_dist, max_dist, have, bt, bi);
+    rect_axis_test<T, 0>(S.rects[first + 4], first + 4, r, min_dist, max_dist, have, bt, bi);
+    rect_axis_test<T, 0>(S.rects[first + 5], first + 5, r, min_dist, max_dist, have, bt, bi);
+    *t_out = bt;
+    *prim_out = bi;
+    return have;
+}
+
 // Vec<Arc<dyn Hittable>>::hit over a Block's sides / a Spotlight's panes (src/hitting.rs:88-104):
 // every element sees the same [min,max]; strict < keeps the first of equal distances.
 template <typename T, bool UNIFORM>
@@ -362,7 +382,8 @@ __device__ __forceinline__ float round_up(double x) { return __double2float_ru(x
 __device__ __forceinline__ float round_down(float x) { return x; }
 __device__ __forceinline__ float round_up(float x) { return x; }
 
-__device__ __forceinline__ bool box2_hit(const float* lo, const float* hi, const RayF& f, float tmin, float tmax) {
+__device__ __forceinline__ bool box2_hit(const float* lo, const float* hi, const RayF& f, float tmin, float tmax,
+                                         float* entry) {
     float ta = (lo[0] - f.ox) * f.ix, tb = (hi[0] - f.ox) * f.ix;
     tmin = fmaxf(fminf(ta, tb), tmin);
     tmax = fminf(fmaxf(ta, tb), tmax);
@@ -372,6 +393,7 @@ __device__ __forceinline__ bool box2_hit(const float* lo, const float* hi, const
     ta = (lo[2] - f.oz) * f.iz; tb = (hi[2] - f.oz) * f.iz;
     tmin = fmaxf(fminf(ta, tb), tmin);
     tmax = fminf(fmaxf(ta, tb), tmax);
+    *entry = tmin;  // where the ray enters the (padded) box: only used to pick which child to walk first
     return tmax >= tmin;
 }
 
@@ -397,11 +419,14 @@ struct Stack {
     __device__ __forceinline__ int32_t get(int e) const { return base[e * stride]; }
 };
 
-// BVHNode::hit over a triangle BVH (src/hitting.rs:211-229).  The recursion "left with
-// [min,max], then right with [min, min(left.t, max)], right wins if it hits" is a
-// depth-first walk, left child first, with a shrinking upper bound that accepts t <= bound
-// (so the later leaf wins an exact tie, as in the reference).  `root` is a DNode2 whose child 0
-// is the reference's root.
+// BVHNode::hit over a triangle BVH (src/hitting.rs:211-229).  The reference's recursion "left with
+// [min,max], then right with [min, min(left.t, max)], right wins if it hits" returns the leaf with
+// the smallest t and, among leaves with exactly equal t, the one that comes LAST in depth-first
+// (left-first) order.  That answer does not depend on the order in which leaves are tested, so the
+// walk here goes into the nearer child first (the bound shrinks sooner and far subtrees are
+// culled: the reference's fixed left-first order tests ~3x more triangles on the knight) and
+// settles exact ties by the leaf's depth-first rank (DTriangle::dfs_rank, set when the scene is
+// uploaded).  `root` is a DNode2 whose child 0 is the reference's root.
 template <typename T>
 __device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, Stack st, int sp0,
                          T* t_out, int* prim_out) {
@@ -411,17 +436,22 @@ __device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_di
     int sp = sp0;
     int32_t next = root;
     bool found = false;
+    int32_t best_rank = -1;
     for (;;) {
         // One 64-byte fetch decides a level (both children's boxes); leaves that come up - as the
         // chosen child or from the stack - are tested exactly before the next node is fetched.
         const Node2Regs n = load_node2(S.nodes2, next);
         const int32_t c0 = n.child(0), c1 = n.child(1);
-        const bool h0 = c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32);
-        const bool h1 = c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32);
+        float e0, e1;
+        const bool h0 = c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32, &e0);
+        const bool h1 = c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32, &e1);
         next = RT_EMPTY;
-        if (h0) {
+        if (h0 && h1) {
+            const bool far_first = S.ordered && e1 < e0;
+            next = far_first ? c1 : c0;
+            st.put(sp++, far_first ? c0 : c1);
+        } else if (h0) {
             next = c0;
-            if (h1) st.put(sp++, c1);
         } else if (h1) {
             next = c1;
         }
@@ -434,13 +464,17 @@ __device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_di
                 next = st.get(--sp);
             }
             if (next >= 0) break;
-            const int tri = -1 - next;  // leaf: the exact test, against the current bound
+            const int tri = -1 - next;  // leaf: the exact test, against the current bound (t == bound passes)
             T t;
-            if (triangle_hit(S.triangles[tri], r, min_dist, max_dist, &t)) {
-                max_dist = t;
-                bound32 = round_up(t);
-                *prim_out = tri;
-                found = true;
+            const DTriangle<T> tr = S.triangles[tri];
+            if (triangle_hit(tr, r, min_dist, max_dist, &t)) {
+                if (!found || t < max_dist || tr.dfs_rank > best_rank) {
+                    max_dist = t;
+                    bound32 = round_up(t);
+                    *prim_out = tri;
+                    best_rank = tr.dfs_rank;
+                    found = true;
+                }
             }
             next = RT_EMPTY;
         }
@@ -465,7 +499,10 @@ __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& worl
     const DObject ob = rec<UNIFORM>(&S.objects[oi]);
     Ray<T> r = world_ray;
     if (ob.xform >= 0) r = to_object_space(rec<UNIFORM>(&S.xforms[ob.xform]), world_ray);
-    if (ob.kind == RT_OBJ_RECTS) return rects_hit<T, UNIFORM>(S, r, ob.first, ob.count, min_dist, max_dist, t_out, prim_out);
+    if (ob.kind == RT_OBJ_RECTS) {
+        if (!UNIFORM && ob.block6) return block6_hit(S, r, ob.first, min_dist, max_dist, t_out, prim_out);
+        return rects_hit<T, UNIFORM>(S, r, ob.first, ob.count, min_dist, max_dist, t_out, prim_out);
+    }
     if constexpr ((FEAT & FEAT_SPHERES) != 0) {
         if (ob.kind == RT_OBJ_SPHERE) {
             const DSphere<T> s = rec<UNIFORM>(&S.spheres[ob.first]);
@@ -639,6 +676,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
             float bound32 = round_up(bound);
             int sp = 0;
             int32_t next = S.tlas_root;
+            int32_t best_rank = -1;
             for (;;) {  // one step per iteration: one leaf (exact object test) or one node (two box tests)
                 if (next == RT_EMPTY) {
                     if (sp == 0) break;
@@ -649,22 +687,32 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                     T th;
                     int prim;
                     if (object_hit<T, false, FEAT>(S, oi, ray, min_dist, bound, st, sp, path, depth, &th, &prim)) {
-                        bound = th;
-                        bound32 = round_up(th);
-                        w.obj = oi;
-                        w.prim = prim;
-                        found = true;
+                        // nearer-child-first walk (see blas_hit): among exactly equal distances the leaf
+                        // that is last in the reference's depth-first order wins
+                        const int32_t rank = S.objects[oi].dfs_rank;
+                        if (!found || th < bound || rank > best_rank) {
+                            bound = th;
+                            bound32 = round_up(th);
+                            w.obj = oi;
+                            w.prim = prim;
+                            best_rank = rank;
+                            found = true;
+                        }
                     }
                     next = RT_EMPTY;
                 } else {
                     const Node2Regs n = load_node2(S.nodes2, next);
                     const int32_t c0 = n.child(0), c1 = n.child(1);
-                    const bool h0 = c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32);
-                    const bool h1 = c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32);
+                    float e0, e1;
+                    const bool h0 = c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32, &e0);
+                    const bool h1 = c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32, &e1);
                     next = RT_EMPTY;
-                    if (h0) {
+                    if (h0 && h1) {
+                        const bool far_first = S.ordered && e1 < e0;
+                        next = far_first ? c1 : c0;
+                        st.put(sp++, far_first ? c0 : c1);
+                    } else if (h0) {
                         next = c0;
-                        if (h1) st.put(sp++, c1);
                     } else if (h1) {
                         next = c1;
                     }
@@ -710,10 +758,15 @@ struct Surface {  // HitRecord, src/hitting.rs:33-41
 // primitive, HitRecord::new's face logic (src/hitting.rs:57-79), then the normal rotated
 // back to world space as the Rotate*::hit wrappers do (src/transforms.rs:119-121 etc.).
 template <typename T, int FEAT>
-__device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, T t, Winner w) {
+__device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, T t, Winner w, bool want_uv) {
+    // want_uv == false (no material of the scene reads (u, v), and nobody asked for the hit record):
+    // (u, v) stay 0; a rect then needs no object-space ray at all, a sphere no acos / atan2.
     const DObject ob = S.objects[w.obj];
+    const int kind = ob.kind;
+    const bool rect_short = kind == RT_OBJ_RECTS && !want_uv;
     Ray<T> r = world_ray;
-    if (ob.xform >= 0) r = to_object_space(S.xforms[ob.xform], world_ray);
+    if (ob.xform >= 0 && !rect_short) r = to_object_space(S.xforms[ob.xform], world_ray);
+    bool front_known = false;
     Surface<T> sf;
     V3<T> outward = mk((T)1.0, (T)0.0, (T)0.0);
     sf.u = 0;
@@ -722,16 +775,29 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
     bool medium = false, unit_already = false;
     sf.material = 0;
     sf.owner = -1;
-    const int kind = ob.kind;
+    sf.front_face = false;
     if (kind == RT_OBJ_RECTS) {
         const DRect<T>& q = S.rects[w.prim];
         int axis = q.axis;
-        int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
-        T a = comp(r.o, ia) + t * comp(r.d, ia);
-        T b = comp(r.o, ib) + t * comp(r.d, ib);
-        sf.u = (a - q.a0) / (q.a1 - q.a0);
-        sf.v = (b - q.b0) / (q.b1 - q.b0);
         T s = q.facing_positive ? (T)1.0 : (T)-1.0;
+        if (want_uv) {
+            int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
+            T a = comp(r.o, ia) + t * comp(r.d, ia);
+            T b = comp(r.o, ib) + t * comp(r.d, ib);
+            sf.u = (a - q.a0) / (q.a1 - q.a0);
+            sf.v = (b - q.b0) / (q.b1 - q.b0);
+        } else {
+            // front_face = dot(d_object, outward) < 0 = (d_object[axis] * s) < 0 (the other two products
+            // are +-0).  d_object = unit_vector(M d) has the sign of (M d)[axis]: the division by the
+            // length cannot change it, so one matrix row replaces the whole transform.
+            T dn = comp(world_ray.d, axis);
+            if (ob.xform >= 0) {
+                const T* m = S.xforms[ob.xform].m + 3 * axis;
+                dn = m[0] * world_ray.d.x + m[1] * world_ray.d.y + m[2] * world_ray.d.z;
+            }
+            sf.front_face = dn * s < (T)0.0;
+            front_known = true;
+        }
         outward = mk(axis == 0 ? s : (T)0.0, axis == 1 ? s : (T)0.0, axis == 2 ? s : (T)0.0);
         unit_already = true;  // (+-1, 0, 0) / sqrt(1) is itself, bit for bit: skip HitRecord::new's unit_vector
         sf.material = q.material;
@@ -740,13 +806,13 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
     } else if ((FEAT & FEAT_SPHERES) != 0 && kind == RT_OBJ_SPHERE) {
         const DSphere<T>& s = S.spheres[w.prim];
         outward = (r.at(t) - ld3(s.centre)) / s.radius;
-        get_sphere_uv(outward, &sf.u, &sf.v);
+        if (want_uv) get_sphere_uv(outward, &sf.u, &sf.v);
         sf.material = s.material;
         sf.owner = s.owner;
     } else if ((FEAT & FEAT_SPHERES) != 0 && kind == RT_OBJ_MOVING_SPHERE) {
         const DMovingSphere<T>& s = S.moving_spheres[w.prim];
         outward = (r.at(t) - moving_centre(s, r.time)) / s.radius;
-        get_sphere_uv(outward, &sf.u, &sf.v);
+        if (want_uv) get_sphere_uv(outward, &sf.u, &sf.v);
         sf.material = s.material;
         sf.owner = s.owner;
     } else if ((FEAT & (FEAT_FLAT | FEAT_BLAS)) != 0 && (kind == RT_OBJ_TRIANGLE || kind == RT_OBJ_BLAS)) {
@@ -778,7 +844,7 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
         sf.front_face = true;
         sf.normal = outward;
     } else {
-        sf.front_face = dot(r.d, outward) < (T)0.0;
+        if (!front_known) sf.front_face = dot(r.d, outward) < (T)0.0;
         V3<T> n = unit_already ? outward : unit_vector(outward);
         sf.normal = sf.front_face ? n : -n;
     }
@@ -933,7 +999,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
         T t;
         Winner w;
         if (closest_hit<T, MODE>(S, r, min_dist, max_dist, st, path, depth, &t, &w)) {
-            Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(S, r, t, w);
+            Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(S, r, t, w, S.needs_uv != 0 || h.owner != nullptr);
             h.t[i] = t;
             h.nx[i] = sf.normal.x; h.ny[i] = sf.normal.y; h.nz[i] = sf.normal.z;
             h.u[i] = sf.u; h.v[i] = sf.v;
@@ -1194,7 +1260,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_bounce(DScene<T> S, 
                 n = mk((T)0.0, (T)1.0, (T)0.0);
                 mf = (uint32_t)W.rects[w.prim].material | 0x80000000u;
 #else
-                const Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(W, ray, t, w);
+                const Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(W, ray, t, w, S.needs_uv != 0);
                 n = sf.normal; u = sf.u; v = sf.v;
                 mf = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
 #endif

@@ -21,7 +21,8 @@ struct alignas(16) DNode {  // reference-shaped node with its own box (f64: 64 B
 struct alignas(16) DNode2 {
     float lo[2][3], hi[2][3];
     int32_t child[2];
-    int32_t pad[2];
+    int32_t block6;    // RT_OBJ_RECTS with the six sides of a Block in Block::new's order (axes z, z, y, y, x, x)
+    int32_t pad;
 };
 static constexpr int32_t RT_EMPTY = (int32_t)0x80000000;
 
@@ -51,7 +52,8 @@ struct alignas(16) DRect {
 template <typename T>
 struct alignas(16) DTriangle {
     T point[3], vec1[3], vec2[3], normal[3];
-    int32_t material, owner, sub, pad;
+    int32_t material, owner, sub;
+    int32_t dfs_rank;  // position of the triangle's leaf in the depth-first order of its mesh BVH (tie rule)
 };
 
 template <typename T>
@@ -69,7 +71,10 @@ struct alignas(16) DMedium {
 
 struct alignas(16) DObject {
     int32_t kind, xform, first, count;
-    int32_t world_index, pad[3];
+    int32_t world_index;
+    int32_t dfs_rank;  // position of the object's leaf in the depth-first order of the world BVH (tie rule)
+    int32_t block6;    // RT_OBJ_RECTS with the six sides of a Block in Block::new's order (axes z, z, y, y, x, x)
+    int32_t pad;
 };
 
 template <typename T>
@@ -113,7 +118,10 @@ struct DScene {
     const int32_t* top_list;
     const int32_t* sweep;  // leaves (object indices) of a small world BVH in depth-first order; n_sweep == 0: walk the tree
     int32_t n_top, tlas_root /* DNode2 super-root */, tlas_root_own /* DNode index */, n_sweep;
-    int32_t lean, pad_[3];  // lean: every object is a rect list or a sphere (no meshes, media, planes, lone triangles)
+    int32_t lean;     // every object is a rect list or a sphere (no meshes, media, planes, lone triangles)
+    int32_t ordered;  // tree walks enter the nearer child first (results are the same either way)
+    int32_t needs_uv;  // some material reads (u, v): image textures, checkers
+    int32_t pad_;
     DCamera<T> camera;
     DSky<T> sky;
 };
