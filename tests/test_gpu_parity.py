@@ -254,3 +254,43 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         r.render_rows(8, 8, 0, 9, 1, 1)
     rgb8, sums, st = r.render_rows(8, 8, 0, 8, 2, 0)   # max_bounces 0: cast_ray returns black at once
     assert st.rays == 0 and not sums.any() and not rgb8.any()
+
+
+# ---------------------------------------------------------------- every traversal layout gives the same answer
+# The library picks a traversal per scene (sweep of a few objects, own-box nodes in LDS, DNode2 tree
+# walk nearer-child-first, fused extend+shade).  They are different programs for the same function:
+# the images must agree bit for bit, and so must the hits.  The environment switches are read when a
+# scene is uploaded (RT_SWEEP_MAX, RT_ORDERED) / when a render starts (RT_FUSE).
+@pytest.mark.parametrize(
+    "name, env",
+    [
+        ("cornell", {"RT_SWEEP_MAX": "0"}),                    # own-box nodes in LDS instead of the sweep
+        ("cornell", {"RT_FUSE": "0"}),                         # extend, then shade, instead of k_bounce
+        ("cornell", {"RT_SWEEP_MAX": "0", "RT_FUSE": "1"}),    # fused kernel over the LDS tree walk
+        ("blue_ball", {"RT_SWEEP_MAX": "0"}),
+        ("blocks_ball", {"RT_ORDERED": "0"}),                  # reference (left-first) order in the DNode2 walk
+        ("blocks_ball", {"RT_FUSE": "1"}),
+        ("knight", {"RT_ORDERED": "0"}),
+        ("globe", {"RT_SWEEP_MAX": "0", "RT_FUSE": "0"}),
+    ],
+)
+def test_traversal_layouts_agree_bit_for_bit(rt, gpu_scenes, name, env, monkeypatch):
+    sc, default_renderer = gpu_scenes(name)
+    W = 96
+    H = sc.image_height(W)
+    rgb8_a, sums_a, st_a = default_renderer.render_rows(W, H, 0, H, 8, 20, seed=77)
+    rays = np.zeros(4096, dtype=rt.RAY_DTYPE)
+    prim = default_renderer.primary_rays(W, H, 0, H, 0, seed=77)
+    rays[:] = prim[np.linspace(0, len(prim) - 1, 4096).astype(int)]
+    hits_a = default_renderer.trace(rays, seed=5)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = rt.Renderer(device=0, precision=0)
+    other.upload(sc)
+    rgb8_b, sums_b, st_b = other.render_rows(W, H, 0, H, 8, 20, seed=77)
+    hits_b = other.trace(rays, seed=5)
+    assert st_a.rays == st_b.rays
+    assert np.array_equal(sums_a, sums_b)
+    assert np.array_equal(rgb8_a, rgb8_b)
+    for field in ("hit", "owner", "sub", "world_index", "front_face", "material", "t", "p", "n", "u", "v"):
+        assert np.array_equal(hits_a[field], hits_b[field]), field
