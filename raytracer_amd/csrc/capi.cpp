@@ -210,9 +210,11 @@ struct Engine : EngineBase {
     uint64_t max_paths;
     bool have_scene = false;
     int stack_depth = 16;
+    int stack_need4 = 0;  // stack entries a four-wide mesh walk can need (0: no four-wide trees)
     rtd::DScene<T> S;
     DevBuf<rtd::DNode2> nodes2;
     size_t n_nodes2 = 0;
+    DevBuf<rtd::DNode4> nodes4;
     DevBuf<rtd::DNode<T>> nodes_own;  // only kept when the scene is small enough for LDS staging
     DevBuf<rtd::DObject> objects;
     DevBuf<rtd::DXform<T>> xforms;
@@ -271,6 +273,32 @@ struct Engine : EngineBase {
             nodes2.upload(v);
             n_nodes2 = v.size();
         }
+        // Four-wide mesh trees (RT_BVH4=0 in the environment keeps the binary walk for A/B runs).
+        std::vector<int32_t> root4(d.n_nodes, -1);
+        S.nodes4 = nullptr;
+        {
+            const char* e = std::getenv("RT_BVH4");
+            std::vector<rtd::DNode4> v;
+            int need = 0;
+            if (!(e && e[0] == '0')) {
+                const float pad = box_pad(d);
+                for (uint64_t i = 0; i < d.n_objects; i++)
+                    if (d.objects[i].kind == RT_OBJ_BLAS && root4[d.objects[i].first] < 0) {
+                        int need_here = 0;
+                        root4[d.objects[i].first] = build_nodes4(d, d.objects[i].first, pad, v, &need_here);
+                        need = std::max(need, need_here);
+                    }
+            }
+            // the walk keeps up to 3 siblings per level on the stack; fall back to the binary tree if a mesh
+            // could overflow the deepest stack class
+            if (!v.empty()) {
+                nodes4.upload(v);
+                S.nodes4 = nodes4.p;
+                stack_need4 = need + 2;
+            } else {
+                stack_need4 = 0;
+            }
+        }
         {
             std::vector<rtd::DObject> v(d.n_objects);
             for (size_t i = 0; i < v.size(); i++) {
@@ -283,7 +311,7 @@ struct Engine : EngineBase {
                         if (d.rects[o.first + k].axis != axes[k]) block6 = 0;
                 }
                 v[i] = rtd::DObject{o.kind, o.xform, o.kind == RT_OBJ_BLAS ? root2[o.first] : o.first, o.count, o.world_index,
-                                    ranks.object[i], block6, 0};
+                                    ranks.object[i], block6, o.kind == RT_OBJ_BLAS ? root4[o.first] : -1};
             }
             objects.upload(v);
         }
@@ -396,6 +424,12 @@ struct Engine : EngineBase {
         for (uint64_t i = 0; i < d.n_materials; i++)
             if (d.materials[i].image >= 0 || d.materials[i].type == RT_MAT_CHECKERED) S.needs_uv = 1;
         stack_depth = d.stack_depth;
+        if (S.nodes4) {
+            // A four-wide walk can hold 3 siblings per level; what does not fit the LDS stack class chosen
+            // from the binary depth goes to the per-lane overflow array (RT_STACK_OVERFLOW entries).
+            const int lds_class = stack_depth <= 16 ? 16 : stack_depth <= 32 ? 32 : 64;
+            if (tree_depth(d, d.tlas_root) + 2 + stack_need4 > lds_class + RT_STACK_OVERFLOW) S.nodes4 = nullptr;
+        }
         build_small_scene(d);
         build_sweep(d);
         have_scene = true;
@@ -465,6 +499,113 @@ struct Engine : EngineBase {
         std::memset(&n, 0, sizeof(n));
         n.child[0] = node2_child(d, nd.left, pad, out, n.lo[0], n.hi[0], ranks);
         n.child[1] = node2_child(d, nd.right, pad, out, n.lo[1], n.hi[1], ranks);
+        out[(size_t)me] = n;
+        return me;
+    }
+
+    static int tree_depth(const rt_scene_desc& d, int32_t root) {  // interior levels above the deepest leaf
+        if (root < 0) return 0;
+        int deepest = 0;
+        std::vector<std::pair<int32_t, int>> todo{{root, 0}};
+        while (!todo.empty()) {
+            auto [idx, depth] = todo.back();
+            todo.pop_back();
+            const rt_node& nd = d.nodes[idx];
+            if (nd.left < 0) {
+                deepest = std::max(deepest, depth);
+                continue;
+            }
+            todo.push_back({nd.left, depth + 1});
+            todo.push_back({nd.right, depth + 1});
+        }
+        return deepest;
+    }
+
+    // ---- four-wide mesh trees
+    static void padded_box(const rt_node& nd, float pad, float* lo, float* hi) {
+        bool well_formed = true;
+        for (int k = 0; k < 3; k++)
+            if (!(nd.lo[k] <= nd.hi[k]) || !std::isfinite(nd.lo[k]) || !std::isfinite(nd.hi[k])) well_formed = false;
+        for (int k = 0; k < 3; k++) {
+            if (well_formed) {
+                lo[k] = std::nextafterf((float)nd.lo[k] - pad, -INFINITY);
+                hi[k] = std::nextafterf((float)nd.hi[k] + pad, INFINITY);
+                if ((double)lo[k] > nd.lo[k]) lo[k] = std::nextafterf(lo[k], -INFINITY);
+                if ((double)hi[k] < nd.hi[k]) hi[k] = std::nextafterf(hi[k], INFINITY);
+            } else {
+                lo[k] = -INFINITY;
+                hi[k] = INFINITY;
+            }
+        }
+    }
+    static bool dead_interior(const rt_node& nd) {  // zero-thickness interior box: culled for every ray
+        if (nd.left < 0) return false;
+        bool well_formed = true, flat = false;
+        for (int k = 0; k < 3; k++) {
+            if (!(nd.lo[k] <= nd.hi[k]) || !std::isfinite(nd.lo[k]) || !std::isfinite(nd.hi[k])) well_formed = false;
+            if (nd.lo[k] == nd.hi[k]) flat = true;
+        }
+        return well_formed && flat;
+    }
+    static double half_area(const rt_node& nd) {
+        double e[3];
+        for (int k = 0; k < 3; k++) e[k] = std::max(0.0, nd.hi[k] - nd.lo[k]);
+        double a = e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+        return std::isfinite(a) ? a : 1e300;
+    }
+    // Child reference for reference node `idx` in the four-wide tree; *need = stack entries a walk below it
+    // can hold at once (3 pushed siblings per level in the worst visiting order).
+    static int32_t node4_child(const rt_scene_desc& d, int32_t idx, float pad, std::vector<rtd::DNode4>& out, int* need) {
+        const rt_node& nd = d.nodes[idx];
+        *need = 0;
+        if (nd.left < 0) return nd.left;
+        if (dead_interior(nd)) return rtd::RT_EMPTY;
+        // fold: start from the two children, open the largest interior slot until there are four (order kept)
+        std::vector<int32_t> slots{nd.left, nd.right};
+        while (slots.size() < 4) {
+            int pick = -1;
+            double best = -1.0;
+            for (size_t k = 0; k < slots.size(); k++) {
+                const rt_node& c = d.nodes[slots[k]];
+                if (c.left < 0 || dead_interior(c)) continue;
+                double a = half_area(c);
+                if (a > best) {
+                    best = a;
+                    pick = (int)k;
+                }
+            }
+            if (pick < 0) break;
+            const rt_node& c = d.nodes[slots[(size_t)pick]];
+            const int32_t l = c.left, r = c.right;
+            slots[(size_t)pick] = l;
+            slots.insert(slots.begin() + pick + 1, r);
+        }
+        const int32_t me = (int32_t)out.size();
+        out.emplace_back();
+        rtd::DNode4 n;
+        std::memset(&n, 0, sizeof(n));
+        int deepest = 0, live = 0;
+        for (int k = 0; k < 4; k++) {
+            n.child[k] = rtd::RT_EMPTY;
+            if ((size_t)k >= slots.size()) continue;
+            padded_box(d.nodes[slots[(size_t)k]], pad, n.lo[k], n.hi[k]);
+            int below = 0;
+            n.child[k] = node4_child(d, slots[(size_t)k], pad, out, &below);
+            if (n.child[k] != rtd::RT_EMPTY) live++;
+            deepest = std::max(deepest, below);
+        }
+        out[(size_t)me] = n;
+        *need = std::max(0, live - 1) + deepest;
+        return me;
+    }
+    static int32_t build_nodes4(const rt_scene_desc& d, int32_t root, float pad, std::vector<rtd::DNode4>& out, int* need) {
+        const int32_t me = (int32_t)out.size();
+        out.emplace_back();
+        rtd::DNode4 n;
+        std::memset(&n, 0, sizeof(n));
+        for (int k = 0; k < 4; k++) n.child[k] = rtd::RT_EMPTY;
+        padded_box(d.nodes[root], pad, n.lo[0], n.hi[0]);
+        n.child[0] = node4_child(d, root, pad, out, need);
         out[(size_t)me] = n;
         return me;
     }

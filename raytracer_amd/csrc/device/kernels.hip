@@ -418,6 +418,19 @@ struct Stack {
     __device__ __forceinline__ void put(int e, int32_t v) { base[e * stride] = v; }
     __device__ __forceinline__ int32_t get(int e) const { return base[e * stride]; }
 };
+// The same with a private array behind it for entries beyond `cap`: a four-wide walk keeps up to 3
+// siblings per level on the stack, which in its worst visiting order is more than the LDS part holds.
+struct DeepStack {
+    int32_t* base;
+    int stride;
+    int cap;
+    int32_t* overflow;
+    __device__ __forceinline__ void put(int e, int32_t v) {
+        if (e < cap) base[e * stride] = v;
+        else overflow[e - cap] = v;
+    }
+    __device__ __forceinline__ int32_t get(int e) const { return e < cap ? base[e * stride] : overflow[e - cap]; }
+};
 
 // BVHNode::hit over a triangle BVH (src/hitting.rs:211-229).  The reference's recursion "left with
 // [min,max], then right with [min, min(left.t, max)], right wins if it hits" returns the leaf with
@@ -427,8 +440,8 @@ struct Stack {
 // culled: the reference's fixed left-first order tests ~3x more triangles on the knight) and
 // settles exact ties by the leaf's depth-first rank (DTriangle::dfs_rank, set when the scene is
 // uploaded).  `root` is a DNode2 whose child 0 is the reference's root.
-template <typename T>
-__device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, Stack st, int sp0,
+template <typename T, typename ST>
+__device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, ST st, int sp0,
                          T* t_out, int* prim_out) {
     const RayF f = ray_f32(r);
     const float tmin32 = round_down(min_dist);
@@ -483,6 +496,88 @@ __device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_di
     return found;
 }
 
+struct alignas(16) Node4Regs {  // a DNode4 fetched as eight 16-byte loads
+    uint4 q[8];
+    __device__ __forceinline__ const float* lo(int c) const { return (const float*)q + 3 * c; }
+    __device__ __forceinline__ const float* hi(int c) const { return (const float*)q + 12 + 3 * c; }
+    __device__ __forceinline__ int32_t child(int c) const { return ((const int32_t*)q)[24 + c]; }
+};
+__device__ __forceinline__ Node4Regs load_node4(const DNode4* nodes, int idx) {
+    const uint4* p = (const uint4*)(nodes + idx);
+    Node4Regs n;
+#pragma unroll
+    for (int k = 0; k < 8; k++) n.q[k] = p[k];
+    return n;
+}
+__device__ __forceinline__ void order2(float& ka, int32_t& ca, float& kb, int32_t& cb) {  // compare-exchange
+    const bool swap = kb < ka;
+    const float k0 = swap ? kb : ka, k1 = swap ? ka : kb;
+    const int32_t c0 = swap ? cb : ca, c1 = swap ? ca : cb;
+    ka = k0; kb = k1; ca = c0; cb = c1;
+}
+
+// The same walk as blas_hit over the four-wide tree: one 128-byte fetch decides two levels of the
+// reference's tree, the children that are hit are visited nearest first (S.ordered) or in the
+// reference's left-to-right order, exact ties go to the higher depth-first rank.
+template <typename T, typename ST>
+__device__ bool blas_hit4(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, ST st, int sp0,
+                          T* t_out, int* prim_out) {
+    const RayF f = ray_f32(r);
+    const float tmin32 = round_down(min_dist);
+    float bound32 = round_up(max_dist);
+    const float MISS = __int_as_float(0x7f800000);
+    int sp = sp0;
+    int32_t next = root;
+    bool found = false;
+    int32_t best_rank = -1;
+    for (;;) {
+        const Node4Regs n = load_node4(S.nodes4, next);
+        float k0, k1, k2, k3;
+        int32_t c0 = n.child(0), c1 = n.child(1), c2 = n.child(2), c3 = n.child(3);
+        {
+            float e;
+            k0 = (c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32, &e)) ? (S.ordered ? e : 0.0f) : MISS;
+            k1 = (c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32, &e)) ? (S.ordered ? e : 1.0f) : MISS;
+            k2 = (c2 != RT_EMPTY && box2_hit(n.lo(2), n.hi(2), f, tmin32, bound32, &e)) ? (S.ordered ? e : 2.0f) : MISS;
+            k3 = (c3 != RT_EMPTY && box2_hit(n.lo(3), n.hi(3), f, tmin32, bound32, &e)) ? (S.ordered ? e : 3.0f) : MISS;
+        }
+        order2(k0, c0, k1, c1);
+        order2(k2, c2, k3, c3);
+        order2(k0, c0, k2, c2);
+        order2(k1, c1, k3, c3);
+        order2(k1, c1, k2, c2);
+        if (k3 < MISS) st.put(sp++, c3);
+        if (k2 < MISS) st.put(sp++, c2);
+        if (k1 < MISS) st.put(sp++, c1);
+        next = k0 < MISS ? c0 : RT_EMPTY;
+        for (;;) {
+            if (next == RT_EMPTY) {
+                if (sp == sp0) {
+                    *t_out = max_dist;
+                    return found;
+                }
+                next = st.get(--sp);
+            }
+            if (next >= 0) break;
+            const int tri = -1 - next;  // leaf: the exact test, against the current bound (t == bound passes)
+            T t;
+            const DTriangle<T> tr = S.triangles[tri];
+            if (triangle_hit(tr, r, min_dist, max_dist, &t)) {
+                if (!found || t < max_dist || tr.dfs_rank > best_rank) {
+                    max_dist = t;
+                    bound32 = round_up(t);
+                    *prim_out = tri;
+                    best_rank = tr.dfs_rank;
+                    found = true;
+                }
+            }
+            next = RT_EMPTY;
+        }
+    }
+    *t_out = max_dist;
+    return found;
+}
+
 struct Winner {
     int obj;   // rt_object index of the instance that was hit (-1: none)
     int prim;  // index into the array of the object's kind (rect / triangle / ... / medium)
@@ -491,11 +586,12 @@ struct Winner {
 // Hittable::hit of one non-medium object instance with bounds [min_dist, max_dist].
 // FEAT: which object kinds a kernel variant compiles in besides rect lists (scenes made of walls,
 // boxes and spheres get a much smaller kernel that needs no scratch memory).
-enum { FEAT_SPHERES = 1, FEAT_FLAT = 2 /* Triangle / Plane objects */, FEAT_BLAS = 4, FEAT_MEDIA = 8, FEAT_ALL = 15 };
+enum { FEAT_SPHERES = 1, FEAT_FLAT = 2 /* Triangle / Plane objects */, FEAT_BLAS = 4, FEAT_MEDIA = 8, FEAT_ALL = 15,
+       FEAT_BLAS4 = 16 /* meshes are walked through the four-wide tree */ };
 
-template <typename T, bool UNIFORM, int FEAT>
+template <typename T, bool UNIFORM, int FEAT, typename ST>
 __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist,
-                                  Stack st, int sp, T* t_out, int* prim_out) {
+                                  ST st, int sp, T* t_out, int* prim_out) {
     const DObject ob = rec<UNIFORM>(&S.objects[oi]);
     Ray<T> r = world_ray;
     if (ob.xform >= 0) r = to_object_space(rec<UNIFORM>(&S.xforms[ob.xform]), world_ray);
@@ -531,7 +627,10 @@ __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& worl
         }
     }
     if constexpr ((FEAT & FEAT_BLAS) != 0) {
-        if (ob.kind == RT_OBJ_BLAS) return blas_hit(S, r, ob.first, min_dist, max_dist, st, sp, t_out, prim_out);
+        if (ob.kind == RT_OBJ_BLAS) {
+            if constexpr ((FEAT & FEAT_BLAS4) != 0) return blas_hit4(S, r, ob.first4, min_dist, max_dist, st, sp, t_out, prim_out);
+            else return blas_hit(S, r, ob.first, min_dist, max_dist, st, sp, t_out, prim_out);
+        }
     }
     return false;
 }
@@ -553,8 +652,8 @@ __device__ __noinline__ T medium_log_draw(PathRef path, uint32_t rng_key, uint32
     return log(rng.next());
 }
 
-template <typename T, bool UNIFORM, int FEAT>
-__device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist, Stack st,
+template <typename T, bool UNIFORM, int FEAT, typename ST>
+__device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist, ST st,
                            int sp, PathRef path, uint32_t depth, T* t_out, int* prim_out) {
     const DObject ob = rec<UNIFORM>(&S.objects[oi]);
     if ((FEAT & FEAT_MEDIA) == 0 || ob.kind != RT_OBJ_MEDIUM)
@@ -583,11 +682,14 @@ __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, 
 
 // world.hit(ray, min, max): the top-level Vec (src/hitting.rs:188-194 -> :88-104) over the
 // world BVH and the unbounded objects; inside the BVH, BVHNode::hit (:211-229).
-enum { WALK_NODE2 = 0, WALK_OWN_BOX_LDS = 1, WALK_SWEEP = 2, WALK_SWEEP_LEAN = 3 /* rect lists and spheres only */ };
-template <int MODE> struct WalkFeat { static constexpr int value = MODE == WALK_SWEEP_LEAN ? FEAT_SPHERES : FEAT_ALL; };
+enum { WALK_NODE2 = 0, WALK_OWN_BOX_LDS = 1, WALK_SWEEP = 2, WALK_SWEEP_LEAN = 3 /* rect lists and spheres only */,
+       WALK_NODE2_MESH4 = 4 /* WALK_NODE2 with four-wide mesh trees */ };
+template <int MODE> struct WalkFeat {
+    static constexpr int value = MODE == WALK_SWEEP_LEAN ? FEAT_SPHERES : MODE == WALK_NODE2_MESH4 ? (FEAT_ALL | FEAT_BLAS4) : FEAT_ALL;
+};
 
-template <typename T, int MODE>
-__device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T max_dist, Stack st, PathRef path,
+template <typename T, int MODE, typename ST>
+__device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T max_dist, ST st, PathRef path,
                             uint32_t depth, T* t_out, Winner* w_out) {
     constexpr bool SWEEP = MODE == WALK_SWEEP || MODE == WALK_SWEEP_LEAN;
     constexpr bool UNI = SWEEP;  // the top-level list is walked in step by all lanes
@@ -854,6 +956,16 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
 
 // ------------------------------------------------------------------ kernels
 constexpr int BLOCK = 256;
+template <int MODE> struct StackFor {
+    typedef Stack type;
+    static constexpr int SPILL = 1;
+    static __device__ __forceinline__ Stack make(int32_t* lds, int, int32_t*) { return Stack{lds, BLOCK}; }
+};
+template <> struct StackFor<WALK_NODE2_MESH4> {
+    typedef DeepStack type;
+    static constexpr int SPILL = RT_STACK_OVERFLOW;
+    static __device__ __forceinline__ DeepStack make(int32_t* lds, int cap, int32_t* spill) { return DeepStack{lds, BLOCK, cap, spill}; }
+};
 // Paths live in fixed tiles of TILE queue slots; tile t of the output queue receives the
 // survivors of tile t of the input queue, packed at its front, and a per-tile count.
 constexpr uint32_t TILE = RT_TILE;
@@ -983,7 +1095,8 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
     __shared__ int32_t lds_stack[STACK * BLOCK];
     constexpr bool LDS_SCENE = MODE == WALK_OWN_BOX_LDS;
     __shared__ uint4 lds_scene[LDS_SCENE ? RT_LDS_SCENE_BYTES / 16 : 1];
-    Stack st{lds_stack + threadIdx.x, BLOCK};
+    int32_t stack_spill[StackFor<MODE>::SPILL];
+    typename StackFor<MODE>::type st = StackFor<MODE>::make(lds_stack + threadIdx.x, STACK, stack_spill);
     if (LDS_SCENE) stage_small_scene(S, small, lds_scene);
     const uint32_t total = tile_offsets[n_tiles];
     const uint32_t lane = threadIdx.x & 63;
@@ -1233,7 +1346,8 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_bounce(DScene<T> S, 
     __shared__ int32_t lds_stack[STACK * BLOCK];
     constexpr bool LDS_SCENE = MODE == WALK_OWN_BOX_LDS;
     __shared__ uint4 lds_scene[LDS_SCENE ? RT_LDS_SCENE_BYTES / 16 : 1];
-    Stack st{lds_stack + threadIdx.x, BLOCK};
+    int32_t stack_spill[StackFor<MODE>::SPILL];
+    typename StackFor<MODE>::type st = StackFor<MODE>::make(lds_stack + threadIdx.x, STACK, stack_spill);
     DScene<T> W = S;  // the traversal's view of the scene (records in LDS for small worlds)
     if (LDS_SCENE) stage_small_scene(W, small, lds_scene);
     const uint32_t lane = threadIdx.x & 63;
@@ -1368,6 +1482,12 @@ void Launch<T>::extend(const DScene<T>& S, const DSmallScene& small, const DBatc
         hipLaunchKernelGGL((k_extend<T, 64, WALK_SWEEP>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (small.blob && stack <= 16)
         hipLaunchKernelGGL((k_extend<T, 16, WALK_OWN_BOX_LDS>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+    else if (S.nodes4 && stack <= 16)
+        hipLaunchKernelGGL((k_extend<T, 16, WALK_NODE2_MESH4>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+    else if (S.nodes4 && stack <= 32)
+        hipLaunchKernelGGL((k_extend<T, 32, WALK_NODE2_MESH4>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+    else if (S.nodes4)
+        hipLaunchKernelGGL((k_extend<T, 64, WALK_NODE2_MESH4>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (stack <= 16)
         hipLaunchKernelGGL((k_extend<T, 16, WALK_NODE2>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (stack <= 32)
@@ -1386,6 +1506,9 @@ void Launch<T>::bounce(const DScene<T>& S, const DSmallScene& small, const DBatc
     else if (S.n_sweep > 0 && stack <= 16) RT_BOUNCE(16, WALK_SWEEP);
     else if (S.n_sweep > 0) RT_BOUNCE(64, WALK_SWEEP);
     else if (small.blob && stack <= 16) RT_BOUNCE(16, WALK_OWN_BOX_LDS);
+    else if (S.nodes4 && stack <= 16) RT_BOUNCE(16, WALK_NODE2_MESH4);
+    else if (S.nodes4 && stack <= 32) RT_BOUNCE(32, WALK_NODE2_MESH4);
+    else if (S.nodes4) RT_BOUNCE(64, WALK_NODE2_MESH4);
     else if (stack <= 16) RT_BOUNCE(16, WALK_NODE2);
     else if (stack <= 32) RT_BOUNCE(32, WALK_NODE2);
     else RT_BOUNCE(64, WALK_NODE2);

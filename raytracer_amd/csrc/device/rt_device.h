@@ -22,9 +22,18 @@ struct alignas(16) DNode2 {
     float lo[2][3], hi[2][3];
     int32_t child[2];
     int32_t block6;    // RT_OBJ_RECTS with the six sides of a Block in Block::new's order (axes z, z, y, y, x, x)
-    int32_t pad;
+    int32_t first4;    // RT_OBJ_BLAS: root in DScene::nodes4
 };
 static constexpr int32_t RT_EMPTY = (int32_t)0x80000000;
+
+// Four-wide traversal node for triangle meshes (128 B): the reference's binary tree with every
+// other level folded away, so a walk takes about half as many dependent fetches.  Children keep
+// the reference's left-to-right order; child references as in DNode2.
+struct alignas(16) DNode4 {
+    float lo[4][3], hi[4][3];
+    int32_t child[4];
+    int32_t pad[4];
+};
 
 template <typename T>
 struct alignas(16) DXform {  // world -> object: p' = m p + b
@@ -74,7 +83,7 @@ struct alignas(16) DObject {
     int32_t world_index;
     int32_t dfs_rank;  // position of the object's leaf in the depth-first order of the world BVH (tie rule)
     int32_t block6;    // RT_OBJ_RECTS with the six sides of a Block in Block::new's order (axes z, z, y, y, x, x)
-    int32_t pad;
+    int32_t first4;    // RT_OBJ_BLAS: root in DScene::nodes4
 };
 
 template <typename T>
@@ -104,6 +113,7 @@ template <typename T>
 struct DScene {
     const DNode<T>* nodes;  // own-box nodes of the world BVH; valid only inside k_extend<.., LDS_SCENE = true>
     const DNode2* nodes2;
+    const DNode4* nodes4;  // mesh BVHs, four-wide (nullptr: walk nodes2)
     const DObject* objects;
     const DXform<T>* xforms;
     const DSphere<T>* spheres;
@@ -152,6 +162,7 @@ struct DHits {
     int32_t *owner, *sub, *world_index;     // only written when non-null (rt_trace)
 };
 static constexpr uint32_t RT_MISS = 0x7fffffffu;
+#define RT_STACK_OVERFLOW 40  // per-lane traversal-stack entries beyond the LDS part (private memory, rarely touched)
 #define RT_TILE 4096u  // queue slots per tile (kernels.hip: TILE)
 
 struct DBatch {      // which pixels / samples the paths of a batch stand for

@@ -271,6 +271,8 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("blocks_ball", {"RT_ORDERED": "0"}),                  # reference (left-first) order in the DNode2 walk
         ("blocks_ball", {"RT_FUSE": "1"}),
         ("knight", {"RT_ORDERED": "0"}),
+        ("knight", {"RT_BVH4": "0"}),                          # binary instead of four-wide mesh tree
+        ("knight", {"RT_BVH4": "0", "RT_ORDERED": "0"}),
         ("globe", {"RT_SWEEP_MAX": "0", "RT_FUSE": "0"}),
     ],
 )
