@@ -280,8 +280,11 @@ struct Engine : EngineBase {
             const char* e = std::getenv("RT_BVH4");
             std::vector<rtd::DNode4> v;
             int need = 0;
-            if (!(e && e[0] == '0')) {
+            int need_world = 0;
+            S.tlas_root4 = -1;
+            if (!(e && e[0] == '0') && d.tlas_root >= 0) {
                 const float pad = box_pad(d);
+                S.tlas_root4 = build_nodes4(d, d.tlas_root, pad, v, &need_world);
                 for (uint64_t i = 0; i < d.n_objects; i++)
                     if (d.objects[i].kind == RT_OBJ_BLAS && root4[d.objects[i].first] < 0) {
                         int need_here = 0;
@@ -294,7 +297,7 @@ struct Engine : EngineBase {
             if (!v.empty()) {
                 nodes4.upload(v);
                 S.nodes4 = nodes4.p;
-                stack_need4 = need + 2;
+                stack_need4 = need + need_world + 3;
             } else {
                 stack_need4 = 0;
             }
@@ -428,7 +431,7 @@ struct Engine : EngineBase {
             // A four-wide walk can hold 3 siblings per level; what does not fit the LDS stack class chosen
             // from the binary depth goes to the per-lane overflow array (RT_STACK_OVERFLOW entries).
             const int lds_class = stack_depth <= 16 ? 16 : stack_depth <= 32 ? 32 : 64;
-            if (tree_depth(d, d.tlas_root) + 2 + stack_need4 > lds_class + RT_STACK_OVERFLOW) S.nodes4 = nullptr;
+            if (stack_need4 > lds_class + RT_STACK_OVERFLOW) S.nodes4 = nullptr;
         }
         build_small_scene(d);
         build_sweep(d);

@@ -777,7 +777,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
             T bound = max_dist;
             float bound32 = round_up(bound);
             int sp = 0;
-            int32_t next = S.tlas_root;
+            int32_t next = MODE == WALK_NODE2_MESH4 ? S.tlas_root4 : S.tlas_root;
             int32_t best_rank = -1;
             for (;;) {  // one step per iteration: one leaf (exact object test) or one node (two box tests)
                 if (next == RT_EMPTY) {
@@ -802,6 +802,24 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                         }
                     }
                     next = RT_EMPTY;
+                } else if constexpr (MODE == WALK_NODE2_MESH4) {  // four-wide step, as in blas_hit4
+                    const float MISS = __int_as_float(0x7f800000);
+                    const Node4Regs n = load_node4(S.nodes4, next);
+                    float k0, k1, k2, k3, e;
+                    int32_t c0 = n.child(0), c1 = n.child(1), c2 = n.child(2), c3 = n.child(3);
+                    k0 = (c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32, &e)) ? (S.ordered ? e : 0.0f) : MISS;
+                    k1 = (c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32, &e)) ? (S.ordered ? e : 1.0f) : MISS;
+                    k2 = (c2 != RT_EMPTY && box2_hit(n.lo(2), n.hi(2), f, tmin32, bound32, &e)) ? (S.ordered ? e : 2.0f) : MISS;
+                    k3 = (c3 != RT_EMPTY && box2_hit(n.lo(3), n.hi(3), f, tmin32, bound32, &e)) ? (S.ordered ? e : 3.0f) : MISS;
+                    order2(k0, c0, k1, c1);
+                    order2(k2, c2, k3, c3);
+                    order2(k0, c0, k2, c2);
+                    order2(k1, c1, k3, c3);
+                    order2(k1, c1, k2, c2);
+                    if (k3 < MISS) st.put(sp++, c3);
+                    if (k2 < MISS) st.put(sp++, c2);
+                    if (k1 < MISS) st.put(sp++, c1);
+                    next = k0 < MISS ? c0 : RT_EMPTY;
                 } else {
                     const Node2Regs n = load_node2(S.nodes2, next);
                     const int32_t c0 = n.child(0), c1 = n.child(1);

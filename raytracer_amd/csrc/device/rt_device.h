@@ -113,7 +113,7 @@ template <typename T>
 struct DScene {
     const DNode<T>* nodes;  // own-box nodes of the world BVH; valid only inside k_extend<.., LDS_SCENE = true>
     const DNode2* nodes2;
-    const DNode4* nodes4;  // mesh BVHs, four-wide (nullptr: walk nodes2)
+    const DNode4* nodes4;  // world and mesh BVHs, four-wide (nullptr: walk nodes2)
     const DObject* objects;
     const DXform<T>* xforms;
     const DSphere<T>* spheres;
@@ -131,7 +131,7 @@ struct DScene {
     int32_t lean;     // every object is a rect list or a sphere (no meshes, media, planes, lone triangles)
     int32_t ordered;  // tree walks enter the nearer child first (results are the same either way)
     int32_t needs_uv;  // some material reads (u, v): image textures, checkers
-    int32_t pad_;
+    int32_t tlas_root4;  // world BVH in nodes4 (valid when nodes4 != nullptr)
     DCamera<T> camera;
     DSky<T> sky;
 };

@@ -270,6 +270,7 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("blue_ball", {"RT_SWEEP_MAX": "0"}),
         ("blocks_ball", {"RT_ORDERED": "0"}),                  # reference (left-first) order in the DNode2 walk
         ("blocks_ball", {"RT_FUSE": "1"}),
+        ("blocks_ball", {"RT_BVH4": "0"}),                     # binary instead of four-wide world tree
         ("knight", {"RT_ORDERED": "0"}),
         ("knight", {"RT_BVH4": "0"}),                          # binary instead of four-wide mesh tree
         ("knight", {"RT_BVH4": "0", "RT_ORDERED": "0"}),
