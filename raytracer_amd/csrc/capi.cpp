@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -427,14 +428,21 @@ struct Engine : EngineBase {
         for (uint64_t i = 0; i < d.n_materials; i++)
             if (d.materials[i].image >= 0 || d.materials[i].type == RT_MAT_CHECKERED) S.needs_uv = 1;
         stack_depth = d.stack_depth;
+        S.stack_cap = 0;
+        if (const char* cap_env = std::getenv("RT_STACK_CAP")) S.stack_cap = (int32_t)std::strtol(cap_env, nullptr, 10);  // tests
         if (S.nodes4) {
             // A four-wide walk can hold 3 siblings per level; what does not fit the LDS stack class chosen
             // from the binary depth goes to the per-lane overflow array (RT_STACK_OVERFLOW entries).
             const int lds_class = stack_depth <= 16 ? 16 : stack_depth <= 32 ? 32 : 64;
-            if (stack_need4 > lds_class + RT_STACK_OVERFLOW) S.nodes4 = nullptr;
+            const int lds_part = S.stack_cap > 0 && S.stack_cap < lds_class ? S.stack_cap : lds_class;
+            if (stack_need4 > lds_part + RT_STACK_OVERFLOW) S.nodes4 = nullptr;
         }
         build_small_scene(d);
         build_sweep(d);
+        if (std::getenv("RT_DEBUG"))
+            std::fprintf(stderr, "rt_upload_scene: objects %llu, stack_depth %d, four-wide %s (stack need %d, lds cap %d), sweep %d%s\n",
+                         (unsigned long long)d.n_objects, stack_depth, S.nodes4 ? "yes" : "no", stack_need4, S.stack_cap,
+                         S.n_sweep, S.lean ? " lean" : "");
         have_scene = true;
     }
 

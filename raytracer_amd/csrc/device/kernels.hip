@@ -1114,7 +1114,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
     constexpr bool LDS_SCENE = MODE == WALK_OWN_BOX_LDS;
     __shared__ uint4 lds_scene[LDS_SCENE ? RT_LDS_SCENE_BYTES / 16 : 1];
     int32_t stack_spill[StackFor<MODE>::SPILL];
-    typename StackFor<MODE>::type st = StackFor<MODE>::make(lds_stack + threadIdx.x, STACK, stack_spill);
+    typename StackFor<MODE>::type st = StackFor<MODE>::make(lds_stack + threadIdx.x, S.stack_cap > 0 && S.stack_cap < STACK ? S.stack_cap : STACK, stack_spill);
     if (LDS_SCENE) stage_small_scene(S, small, lds_scene);
     const uint32_t total = tile_offsets[n_tiles];
     const uint32_t lane = threadIdx.x & 63;
@@ -1365,7 +1365,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_bounce(DScene<T> S, 
     constexpr bool LDS_SCENE = MODE == WALK_OWN_BOX_LDS;
     __shared__ uint4 lds_scene[LDS_SCENE ? RT_LDS_SCENE_BYTES / 16 : 1];
     int32_t stack_spill[StackFor<MODE>::SPILL];
-    typename StackFor<MODE>::type st = StackFor<MODE>::make(lds_stack + threadIdx.x, STACK, stack_spill);
+    typename StackFor<MODE>::type st = StackFor<MODE>::make(lds_stack + threadIdx.x, S.stack_cap > 0 && S.stack_cap < STACK ? S.stack_cap : STACK, stack_spill);
     DScene<T> W = S;  // the traversal's view of the scene (records in LDS for small worlds)
     if (LDS_SCENE) stage_small_scene(W, small, lds_scene);
     const uint32_t lane = threadIdx.x & 63;

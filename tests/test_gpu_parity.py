@@ -274,6 +274,8 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_ORDERED": "0"}),
         ("knight", {"RT_BVH4": "0"}),                          # binary instead of four-wide mesh tree
         ("knight", {"RT_BVH4": "0", "RT_ORDERED": "0"}),
+        ("knight", {"RT_STACK_CAP": "6"}),                     # four-wide walk mostly on the private overflow stack
+        ("blocks_ball", {"RT_STACK_CAP": "3"}),
         ("globe", {"RT_SWEEP_MAX": "0", "RT_FUSE": "0"}),
     ],
 )
