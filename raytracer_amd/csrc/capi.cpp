@@ -396,6 +396,27 @@ struct Engine : EngineBase {
                 v[i].param = (T)m.param;
                 v[i].type = m.type; v[i].image = m.image; v[i].odd = m.odd; v[i].even = m.even;
             }
+            // Checkered: `image` (unused by that type) says whether some part of it, through nested checkers,
+            // is a light; emitted() of any other checker is black whatever part (u, v) selects.
+            for (size_t i = 0; i < v.size(); i++) {
+                if (d.materials[i].type != RT_MAT_CHECKERED) continue;
+                bool emits = false;
+                std::vector<int32_t> todo{(int32_t)i};
+                std::vector<char> seen(v.size(), 0);
+                while (!todo.empty() && !emits) {
+                    const int32_t k = todo.back();
+                    todo.pop_back();
+                    if (seen[(size_t)k]) continue;
+                    seen[(size_t)k] = 1;
+                    const rt_material& mk = d.materials[k];
+                    if (mk.type == RT_MAT_DIFFUSE_LIGHT) emits = true;
+                    if (mk.type == RT_MAT_CHECKERED) {
+                        todo.push_back(mk.odd);
+                        todo.push_back(mk.even);
+                    }
+                }
+                v[i].image = emits ? 1 : 0;
+            }
             materials.upload(v);
         }
         {

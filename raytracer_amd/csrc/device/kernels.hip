@@ -1214,7 +1214,9 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
         {
             int me = mi;
             DMaterial<T> m = S.materials[me];
-            if (m.type == RT_MAT_CHECKERED) {
+            // (a checker none of whose parts is a light emits nothing: m.image == 0 then, set at upload,
+            // and the two f64 sines are skipped)
+            if (m.type == RT_MAT_CHECKERED && m.image != 0) {
                 me = resolve_checkered(S, me, u, v, (T)1.0);
                 m = S.materials[me];
             }

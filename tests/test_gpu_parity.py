@@ -299,3 +299,38 @@ def test_traversal_layouts_agree_bit_for_bit(rt, gpu_scenes, name, env, monkeypa
     assert np.array_equal(rgb8_a, rgb8_b)
     for field in ("hit", "owner", "sub", "world_index", "front_face", "material", "t", "p", "n", "u", "v"):
         assert np.array_equal(hits_a[field], hits_b[field]), field
+
+
+def test_checkers_that_emit_and_checkers_that_do_not(rt, orc):
+    # Checkered::emitted picks a part with sin(k u) sin(k v) (no PI), scatter with sin(k PI u) sin(k PI v)
+    # (src/materials.rs:166-183).  The kernel skips the emitted() selection for a checker none of whose
+    # parts - through nested checkers - is a light: both kinds, nested, against the oracle.
+    text = """{
+      camera: {lookFrom: [0,1.5,-6], lookAt: [0,0.5,0], directionUp: [0,1,0], fieldOfView: 45, aspectRatio: [1,1],
+               aperture: 0, distanceToFocus: 6, startTime: 0, endTime: 1},
+      background: {type: "plainColour", colour: [0.05,0.05,0.1]},
+      textures: {w: {type: "solidColour", colour: [0.8,0.8,0.8]}, g: {type: "solidColour", colour: [0.2,0.6,0.3]},
+                 l: {type: "solidColour", colour: [3,2,1]}},
+      materials: {white: {type: "lambertian", texture: "w"}, green: {type: "lambertian", texture: "g"},
+                  lamp: {type: "diffuseLight", emit: "l"},
+                  dull: {type: "checkered", odd: "white", even: "green", tileDensity: 9},
+                  glow: {type: "checkered", odd: "lamp", even: "green", tileDensity: 7},
+                  deep: {type: "checkered", odd: "dull", even: "glow", tileDensity: 3}},
+      objects: {
+        floor: {type: "rect", corner0: [-4,0,-4], corner1: [4,0,4], facingForward: true, material: "dull"},
+        a: {type: "sphere", centre: [-1.2,1,0], radius: 1, material: "glow"},
+        b: {type: "sphere", centre: [1.2,1,0], radius: 1, material: "deep"},
+      },
+      world: ["floor", "a", "b"],
+    }"""
+    scene = rt.Scene.from_text(text)
+    o = orc.OracleScene.from_text(text)
+    r = rt.Renderer(0)
+    r.upload(scene)
+    W = H = 64
+    rgb8, sums, st = r.render_rows(W, H, 0, H, 16, 12, seed=9)
+    o8, osums, orays = o.render(W, H, 0, H, 16, 12, seed=9, threads=4)
+    close = np.isclose(sums, osums, rtol=1e-6, atol=1e-9).all(axis=2)
+    assert close.mean() >= 0.99
+    assert abs(int(st.rays) - orays) <= 0.002 * orays
+    assert sums.max() > 1.0  # the lamps are seen
