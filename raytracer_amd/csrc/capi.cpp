@@ -246,7 +246,7 @@ struct Engine : EngineBase {
     Engine(hipStream_t st, int cus, uint64_t maxp) : stream(st), num_cus(cus), max_paths(maxp) {
         std::memset(&S, 0, sizeof(S));
         HIP_CHECK(hipHostMalloc((void**)&host_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
-        counts.ensure(2);
+        counts.ensure(4);  // [0] live paths after the last scan, [1] spare, [2] deepest bounce reached inside a tail launch
         ray_total.ensure(1);
     }
     ~Engine() override {
@@ -848,11 +848,16 @@ struct Engine : EngineBase {
         ensure_capacity((size_t)(npix * spb), false);
         sample_rgb.ensure((size_t)(npix * spb) * 3);
         HIP_CHECK(hipMemsetAsync(ray_total.p, 0, sizeof(unsigned long long), stream));
+        HIP_CHECK(hipMemsetAsync(counts.p + 2, 0, sizeof(uint32_t), stream));
+        // RT_TAIL=n (environment): paths alive at or below which the tail launch takes over (0: never).
+        uint32_t tail_threshold = 65536;
+        if (const char* e = std::getenv("RT_TAIL")) tail_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
         size_t ev = 0;
         const bool timing = stats != nullptr;
         // One fused launch per bounce pays off when the traversal is the lean sweep (no stack, no spills:
         // cornell 30.5 -> 25.2 ms); with a divergent tree walk the shading half runs at the walk's low
         // occupancy and loses (knight 95 -> 107 ms).  RT_FUSE=0 / 1 (environment) overrides for A/B runs.
+        const bool debug_counts = std::getenv("RT_DEBUG") != nullptr;
         const char* fuse_env = std::getenv("RT_FUSE");
         const bool fused = fuse_env ? fuse_env[0] != '0' : (S.n_sweep > 0 && S.lean);
         std::vector<std::pair<size_t, int>> spans;  // (first event index, 0 = extend / 1 = shade)
@@ -879,7 +884,7 @@ struct Engine : EngineBase {
                 }
                 if (fused) {  // one launch per bounce; its time is reported as ms_extend
                     rtd::Launch<T>::bounce(S, small, B, queue(in), queue(out), sample_rgb.p, depth, max_bounces,
-                                           tile_offsets.p, tile_counts[out].p, n_tiles, stack_depth, grid, stream);
+                                           tile_offsets.p, tile_counts[out].p, n_tiles, stack_depth, grid, nullptr, stream);
                     if (timing) HIP_CHECK(hipEventRecord(event(ev + 1), stream));
                 } else {
                     rtd::Launch<T>::extend(S, small, B, queue(in), hits(false), nullptr, nullptr, depth, tile_offsets.p,
@@ -901,7 +906,24 @@ struct Engine : EngineBase {
                     // Every 4th bounce: is anything still alive?  (One 4-byte read-back.)
                     HIP_CHECK(hipMemcpyAsync(host_counts, counts.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                     HIP_CHECK(hipStreamSynchronize(stream));
+                    if (debug_counts) std::fprintf(stderr, "  after bounce %u: %u paths alive\n", depth + 1, host_counts[0]);
                     if (host_counts[0] == 0) break;
+                    if (host_counts[0] <= tail_threshold) {
+                        // The few paths left go through all their remaining bounces in ONE launch, each at its
+                        // own pace, instead of one launch per bounce that waits for the slowest ray (k_bounce,
+                        // DTail).  Its time is reported with the extend kernel's.
+                        const rtd::DTail tail{ray_total.p, counts.p + 2};
+                        if (timing) {
+                            spans.push_back({ev, 0});
+                            HIP_CHECK(hipEventRecord(event(ev), stream));
+                        }
+                        rtd::Launch<T>::bounce(S, small, B, queue(out), queue(in), sample_rgb.p, depth + 1, max_bounces,
+                                               tile_offsets.p, tile_counts[in].p, n_tiles, stack_depth, grid_for(host_counts[0]),
+                                               &tail, stream);
+                        if (timing) HIP_CHECK(hipEventRecord(event(ev + 1), stream));
+                        ev += 3;
+                        break;
+                    }
                 }
             }
             rtd::Launch<T>::accumulate(sample_rgb.p, (uint32_t)npix, bns, accum_dev, stream);
@@ -910,7 +932,9 @@ struct Engine : EngineBase {
         if (timing) HIP_CHECK(hipEventRecord(ev_end, stream));
         unsigned long long total = 0;
         HIP_CHECK(hipMemcpyAsync(&total, ray_total.p, sizeof(total), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(host_counts + 2, counts.p + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
+        deepest = std::max(deepest, std::min(host_counts[2], max_bounces));
         if (stats) {
             stats->rays = total;
             stats->paths = npix * ns;

@@ -1360,14 +1360,20 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene<T> S, DBatch B, DQueue<T
 // registers, the ray is read once, and a bounce is one launch.  rt_trace keeps k_extend.
 template <typename T, int STACK, int MODE>
 __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_bounce(DScene<T> S, DSmallScene small, DBatch B, DQueue<T> qin, DQueue<T> qout,
-                                                                    T* sample_rgb, uint32_t depth, uint32_t max_bounces,
+                                                                    T* sample_rgb, uint32_t depth0, uint32_t max_bounces,
                                                                     const uint32_t* __restrict__ tile_offsets,
-                                                                    uint32_t* tile_counts_out, uint32_t n_tiles) {
+                                                                    uint32_t* tile_counts_out, uint32_t n_tiles, DTail tail) {
     __shared__ int32_t lds_stack[STACK * BLOCK];
     constexpr bool LDS_SCENE = MODE == WALK_OWN_BOX_LDS;
     __shared__ uint4 lds_scene[LDS_SCENE ? RT_LDS_SCENE_BYTES / 16 : 1];
     int32_t stack_spill[StackFor<MODE>::SPILL];
     typename StackFor<MODE>::type st = StackFor<MODE>::make(lds_stack + threadIdx.x, S.stack_cap > 0 && S.stack_cap < STACK ? S.stack_cap : STACK, stack_spill);
+    // tail.run: the few paths that are left are carried through ALL their remaining bounces here, each at
+    // its own pace (a launch per bounce would wait for the slowest ray of every bounce: on the knight
+    // ~0.4 ms per bounce for a ray caught inside the glass mesh, 35 times over).  Same streams, same
+    // arithmetic, same image.
+    const bool run_tail = tail.ray_total != nullptr;
+    uint32_t extra_queries = 0, deepest = depth0;
     DScene<T> W = S;  // the traversal's view of the scene (records in LDS for small worlds)
     if (LDS_SCENE) stage_small_scene(W, small, lds_scene);
     const uint32_t lane = threadIdx.x & 63;
@@ -1382,27 +1388,45 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_bounce(DScene<T> S, 
         V3<T> thr;
         uint32_t pid = 0;
         if (valid) {
-            const Ray<T> ray = load_ray(qin, i);
+            Ray<T> ray = load_ray(qin, i);
             pid = qin.pid[i];
             const PathRef path{&B, pid};
-            T t = 0, u = 0, v = 0;
-            V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
-            uint32_t mf = RT_MISS;
-            Winner w;
-            if (closest_hit<T, MODE>(W, ray, (T)0.001, Lim<T>::inf(), st, path, depth, &t, &w)) {  // src/hitting.rs:20-21
-#if defined(RT_EXP) && (RT_EXP & 16)  // timing experiment only: no surface reconstruction
-                n = mk((T)0.0, (T)1.0, (T)0.0);
-                mf = (uint32_t)W.rects[w.prim].material | 0x80000000u;
-#else
-                const Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(W, ray, t, w, S.needs_uv != 0);
-                n = sf.normal; u = sf.u; v = sf.v;
-                mf = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
-#endif
-            }
             thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
-            alive = shade_path(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
+            deepest = depth0 + 1;
+            for (uint32_t depth = depth0;; depth++) {
+                T t = 0, u = 0, v = 0;
+                V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
+                uint32_t mf = RT_MISS;
+                Winner w;
+                if (closest_hit<T, MODE>(W, ray, (T)0.001, Lim<T>::inf(), st, path, depth, &t, &w)) {  // src/hitting.rs:20-21
+#if defined(RT_EXP) && (RT_EXP & 16)  // timing experiment only: no surface reconstruction
+                    n = mk((T)0.0, (T)1.0, (T)0.0);
+                    mf = (uint32_t)W.rects[w.prim].material | 0x80000000u;
+#else
+                    const Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(W, ray, t, w, S.needs_uv != 0);
+                    n = sf.normal; u = sf.u; v = sf.v;
+                    mf = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
+#endif
+                }
+                alive = shade_path(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
+                if (!run_tail || !alive) break;
+                ray = nr;  // the scattered ray is the next bounce's query
+                extra_queries++;
+                deepest = depth + 2;
+            }
+            if (run_tail) alive = false;
         }
         compact_store(alive, tile, nr, thr, pid, qout, tile_counts_out);
+    }
+    if (run_tail) {  // rays and depth statistics of the bounces that were not launches
+        for (int off = 32; off > 0; off >>= 1) {
+            extra_queries += __shfl_xor(extra_queries, off);
+            deepest = max(deepest, (uint32_t)__shfl_xor(deepest, off));
+        }
+        if (lane == 0) {
+            if (extra_queries) atomicAdd(tail.ray_total, (unsigned long long)extra_queries);
+            atomicMax(tail.deepest, deepest);
+        }
     }
 }
 
@@ -1518,10 +1542,11 @@ void Launch<T>::extend(const DScene<T>& S, const DSmallScene& small, const DBatc
 template <typename T>
 void Launch<T>::bounce(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> qin, DQueue<T> qout, T* sample_rgb,
                        uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets, uint32_t* tile_counts_out,
-                       uint32_t n_tiles, int stack, int grid_blocks, hipStream_t st) {
+                       uint32_t n_tiles, int stack, int grid_blocks, const DTail* tail, hipStream_t st) {
+    const DTail tl = tail ? *tail : DTail{nullptr, nullptr};
 #define RT_BOUNCE(STACK, MODE)                                                                                            \
     hipLaunchKernelGGL((k_bounce<T, STACK, MODE>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, qin, qout, sample_rgb, \
-                       depth, max_bounces, tile_offsets, tile_counts_out, n_tiles)
+                       depth, max_bounces, tile_offsets, tile_counts_out, n_tiles, tl)
     if (S.n_sweep > 0 && S.lean) RT_BOUNCE(1, WALK_SWEEP_LEAN);
     else if (S.n_sweep > 0 && stack <= 16) RT_BOUNCE(16, WALK_SWEEP);
     else if (S.n_sweep > 0) RT_BOUNCE(64, WALK_SWEEP);

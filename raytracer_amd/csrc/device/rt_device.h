@@ -174,6 +174,14 @@ struct DBatch {      // which pixels / samples the paths of a batch stand for
     uint64_t seed;
 };
 
+// k_bounce as the tail of a batch: with ray_total != nullptr the kernel carries every path of its
+// input queue through all remaining bounces (nothing is written to the output queue) and adds the
+// closest-hit queries beyond the first / the deepest bounce reached to these counters.
+struct DTail {
+    unsigned long long* ray_total;
+    uint32_t* deepest;
+};
+
 // Launch wrappers (kernels.hip).  `stack` selects the LDS traversal-stack depth (16/32/64).
 template <typename T>
 struct Launch {
@@ -185,7 +193,8 @@ struct Launch {
     // extend + shade of one bounce in one launch (render path).
     static void bounce(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> qin, DQueue<T> qout,
                        T* sample_rgb, uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets,
-                       uint32_t* tile_counts_out, uint32_t n_tiles, int stack, int grid_blocks, hipStream_t st);
+                       uint32_t* tile_counts_out, uint32_t n_tiles, int stack, int grid_blocks, const DTail* tail,
+                       hipStream_t st);
     static void shade(const DScene<T>& S, const DBatch& B, DQueue<T> qin, DHits<T> h, DQueue<T> qout, T* sample_rgb,
                       uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets, uint32_t* tile_counts_out,
                       uint32_t n_tiles, int grid_blocks, hipStream_t st);

@@ -277,6 +277,10 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_STACK_CAP": "6"}),                     # four-wide walk mostly on the private overflow stack
         ("blocks_ball", {"RT_STACK_CAP": "3"}),
         ("globe", {"RT_SWEEP_MAX": "0", "RT_FUSE": "0"}),
+        ("cornell", {"RT_TAIL": "0"}),                         # a launch per bounce to the end, no tail launch
+        ("knight", {"RT_TAIL": "0"}),
+        ("blocks_ball", {"RT_TAIL": "0"}),
+        ("blue_ball", {"RT_TAIL": "1000000000"}),              # the whole render after bounce 4 in the tail launch
     ],
 )
 def test_traversal_layouts_agree_bit_for_bit(rt, gpu_scenes, name, env, monkeypatch):
@@ -295,6 +299,7 @@ def test_traversal_layouts_agree_bit_for_bit(rt, gpu_scenes, name, env, monkeypa
     rgb8_b, sums_b, st_b = other.render_rows(W, H, 0, H, 8, 20, seed=77)
     hits_b = other.trace(rays, seed=5)
     assert st_a.rays == st_b.rays
+    assert st_a.max_depth_reached == st_b.max_depth_reached
     assert np.array_equal(sums_a, sums_b)
     assert np.array_equal(rgb8_a, rgb8_b)
     for field in ("hit", "owner", "sub", "world_index", "front_face", "material", "t", "p", "n", "u", "v"):
