@@ -212,6 +212,7 @@ struct Engine : EngineBase {
     bool have_scene = false;
     int stack_depth = 16;
     int stack_need4 = 0;  // stack entries a four-wide mesh walk can need (0: no four-wide trees)
+    bool sah_trees = false;  // the four-wide trees were regrouped by SAH (else: the reference's grouping, folded)
     rtd::DScene<T> S;
     DevBuf<rtd::DNode2> nodes2;
     size_t n_nodes2 = 0;
@@ -277,30 +278,56 @@ struct Engine : EngineBase {
         // Four-wide mesh trees (RT_BVH4=0 in the environment keeps the binary walk for A/B runs).
         std::vector<int32_t> root4(d.n_nodes, -1);
         S.nodes4 = nullptr;
+        // They are regrouped by SAH (RT_SAH=0: the reference's grouping, folded two levels into one); a
+        // walk keeps up to 3 siblings per level on its stack, and a tree whose worst case would not fit
+        // the stack (LDS class + overflow array) is not used: SAH -> folded reference tree -> binary walk.
+        stack_depth = d.stack_depth;
+        S.stack_cap = 0;
+        if (const char* cap_env = std::getenv("RT_STACK_CAP")) S.stack_cap = (int32_t)std::strtol(cap_env, nullptr, 10);  // tests
+        sah_trees = false;
         {
             const char* e = std::getenv("RT_BVH4");
-            std::vector<rtd::DNode4> v;
-            int need = 0;
-            int need_world = 0;
+            const char* sah_env = std::getenv("RT_SAH");
+            const int lds_class = stack_depth <= 16 ? 16 : stack_depth <= 32 ? 32 : 64;
+            const int lds_part = S.stack_cap > 0 && S.stack_cap < lds_class ? S.stack_cap : lds_class;
+            const float pad = box_pad(d);
             S.tlas_root4 = -1;
-            if (!(e && e[0] == '0') && d.tlas_root >= 0) {
-                const float pad = box_pad(d);
-                S.tlas_root4 = build_nodes4(d, d.tlas_root, pad, v, &need_world);
+            stack_need4 = 0;
+            for (int use_sah = (sah_env && sah_env[0] == '0') ? 0 : 1; use_sah >= 0; use_sah--) {
+                if ((e && e[0] == '0') || d.tlas_root < 0) break;
+                std::vector<rtd::DNode4> v;
+                int need = 0, need_world = 0;
+                auto build = [&](int32_t root, int* need_out) {
+                    int32_t r = -1;
+                    if (use_sah && build_sah4(d, root, pad, v, &r, need_out)) return r;
+                    return build_nodes4(d, root, pad, v, need_out);
+                };
+                std::fill(root4.begin(), root4.end(), -1);
+                {
+                    const int meshes_too = use_sah;
+                    if (sah_env && sah_env[0] == '2') use_sah = 0;  // RT_SAH=2: meshes only
+                    S.tlas_root4 = build(d.tlas_root, &need_world);
+                    use_sah = meshes_too;
+                }
                 for (uint64_t i = 0; i < d.n_objects; i++)
                     if (d.objects[i].kind == RT_OBJ_BLAS && root4[d.objects[i].first] < 0) {
                         int need_here = 0;
-                        root4[d.objects[i].first] = build_nodes4(d, d.objects[i].first, pad, v, &need_here);
+                        root4[d.objects[i].first] = build(d.objects[i].first, &need_here);
                         need = std::max(need, need_here);
                     }
-            }
-            // the walk keeps up to 3 siblings per level on the stack; fall back to the binary tree if a mesh
-            // could overflow the deepest stack class
-            if (!v.empty()) {
-                nodes4.upload(v);
-                S.nodes4 = nodes4.p;
                 stack_need4 = need + need_world + 3;
-            } else {
-                stack_need4 = 0;
+                if (stack_need4 <= lds_part + RT_STACK_OVERFLOW) {
+                    if (std::getenv("RT_DEBUG") && v[(size_t)S.tlas_root4].child[0] >= 0) {
+                        const rtd::DNode4& w = v[(size_t)v[(size_t)S.tlas_root4].child[0]];
+                        for (int k = 0; k < 4; k++)
+                            std::fprintf(stderr, "  world slot %d: child %d  [%g %g %g] - [%g %g %g]\n", k, w.child[k], w.lo[k][0], w.lo[k][1],
+                                         w.lo[k][2], w.hi[k][0], w.hi[k][1], w.hi[k][2]);
+                    }
+                    nodes4.upload(v);
+                    S.nodes4 = nodes4.p;
+                    sah_trees = use_sah != 0;
+                    break;
+                }
             }
         }
         {
@@ -445,25 +472,21 @@ struct Engine : EngineBase {
         // RT_ORDERED=0 (environment) walks trees in the reference's fixed left-first order (A/B runs).
         const char* ordered_env = std::getenv("RT_ORDERED");
         S.ordered = !(ordered_env && ordered_env[0] == '0');
+        S.has_meshes = S.has_media = 0;
+        for (uint64_t i = 0; i < d.n_objects; i++) {
+            if (d.objects[i].kind == RT_OBJ_BLAS) S.has_meshes = 1;
+            if (d.objects[i].kind == RT_OBJ_MEDIUM) S.has_media = 1;
+        }
+        if (const char* e = std::getenv("RT_FEATURES"); e && e[0] == 'a') S.has_meshes = S.has_media = 1;  // "all": the general kernel (A/B runs, tests)
         S.needs_uv = 0;
         for (uint64_t i = 0; i < d.n_materials; i++)
             if (d.materials[i].image >= 0 || d.materials[i].type == RT_MAT_CHECKERED) S.needs_uv = 1;
-        stack_depth = d.stack_depth;
-        S.stack_cap = 0;
-        if (const char* cap_env = std::getenv("RT_STACK_CAP")) S.stack_cap = (int32_t)std::strtol(cap_env, nullptr, 10);  // tests
-        if (S.nodes4) {
-            // A four-wide walk can hold 3 siblings per level; what does not fit the LDS stack class chosen
-            // from the binary depth goes to the per-lane overflow array (RT_STACK_OVERFLOW entries).
-            const int lds_class = stack_depth <= 16 ? 16 : stack_depth <= 32 ? 32 : 64;
-            const int lds_part = S.stack_cap > 0 && S.stack_cap < lds_class ? S.stack_cap : lds_class;
-            if (stack_need4 > lds_part + RT_STACK_OVERFLOW) S.nodes4 = nullptr;
-        }
         build_small_scene(d);
         build_sweep(d);
         if (std::getenv("RT_DEBUG"))
             std::fprintf(stderr, "rt_upload_scene: objects %llu, stack_depth %d, four-wide %s (stack need %d, lds cap %d), sweep %d%s\n",
-                         (unsigned long long)d.n_objects, stack_depth, S.nodes4 ? "yes" : "no", stack_need4, S.stack_cap,
-                         S.n_sweep, S.lean ? " lean" : "");
+                         (unsigned long long)d.n_objects, stack_depth, S.nodes4 ? (sah_trees ? "sah" : "folded") : "no", stack_need4,
+                         S.stack_cap, S.n_sweep, S.lean ? " lean" : "");
         have_scene = true;
     }
 
@@ -640,6 +663,203 @@ struct Engine : EngineBase {
         n.child[0] = node4_child(d, root, pad, out, need);
         out[(size_t)me] = n;
         return me;
+    }
+
+    // ---- four-wide trees rebuilt with the surface-area heuristic.
+    // The reference's tree (object-median split, src/hitting.rs:147-197) only decides which leaves a
+    // ray gets to test; the answer - nearest leaf, exact ties to the later one in the reference's
+    // depth-first order - is kept by the walk's tie rule (dfs_rank), whatever the tree.  So the same
+    // leaves (minus those under a zero-thickness interior box, which the reference never reaches)
+    // are regrouped top-down by binned SAH, four children per node.
+    struct SahLeaf {
+        int32_t ref;
+        float lo[3], hi[3], c[3];
+    };
+    struct SahPart {
+        size_t lo, hi;
+        float blo[3], bhi[3];
+        double area;
+    };
+    static bool collect_leaves(const rt_scene_desc& d, int32_t root, float pad, std::vector<SahLeaf>& out) {
+        std::vector<int32_t> todo{root};
+        while (!todo.empty()) {
+            const rt_node& nd = d.nodes[todo.back()];
+            todo.pop_back();
+            if (nd.left >= 0) {
+                if (dead_interior(nd)) continue;
+                todo.push_back(nd.right);
+                todo.push_back(nd.left);
+                continue;
+            }
+            SahLeaf l;
+            l.ref = nd.left;
+            padded_box(nd, pad, l.lo, l.hi);
+            for (int k = 0; k < 3; k++) {
+                if (!std::isfinite(l.lo[k]) || !std::isfinite(l.hi[k])) return false;  // malformed bounds: keep the reference's tree
+                l.c[k] = 0.5f * l.lo[k] + 0.5f * l.hi[k];
+            }
+            out.push_back(l);
+        }
+        return true;
+    }
+    static double box_area(const float* lo, const float* hi) {
+        const double e0 = (double)hi[0] - lo[0], e1 = (double)hi[1] - lo[1], e2 = (double)hi[2] - lo[2];
+        return e0 * e1 + e1 * e2 + e2 * e0;
+    }
+    static SahPart make_part(const std::vector<SahLeaf>& L, size_t lo, size_t hi) {
+        SahPart p;
+        p.lo = lo;
+        p.hi = hi;
+        for (int k = 0; k < 3; k++) {
+            p.blo[k] = INFINITY;
+            p.bhi[k] = -INFINITY;
+        }
+        for (size_t i = lo; i < hi; i++)
+            for (int k = 0; k < 3; k++) {
+                p.blo[k] = std::min(p.blo[k], L[i].lo[k]);
+                p.bhi[k] = std::max(p.bhi[k], L[i].hi[k]);
+            }
+        p.area = box_area(p.blo, p.bhi);
+        return p;
+    }
+    // Splits L[lo, hi) (>= 2 leaves) in place; returns the first index of the right part.
+    static size_t sah_split(std::vector<SahLeaf>& L, size_t lo, size_t hi) {
+        constexpr int BINS = 32;
+        float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = lo; i < hi; i++)
+            for (int k = 0; k < 3; k++) {
+                cmin[k] = std::min(cmin[k], L[i].c[k]);
+                cmax[k] = std::max(cmax[k], L[i].c[k]);
+            }
+        int best_axis = -1, best_bin = 0;
+        double best_cost = INFINITY;
+        float best_scale = 0.0f;
+        for (int axis = 0; axis < 3; axis++) {
+            const float extent = cmax[axis] - cmin[axis];
+            if (!(extent > 0.0f)) continue;
+            const float scale = (float)BINS / extent;
+            struct Bin {
+                size_t n = 0;
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            } bins[BINS];
+            for (size_t i = lo; i < hi; i++) {
+                const int b = std::min(BINS - 1, (int)((L[i].c[axis] - cmin[axis]) * scale));
+                bins[b].n++;
+                for (int k = 0; k < 3; k++) {
+                    bins[b].lo[k] = std::min(bins[b].lo[k], L[i].lo[k]);
+                    bins[b].hi[k] = std::max(bins[b].hi[k], L[i].hi[k]);
+                }
+            }
+            double right_area[BINS];
+            size_t right_n[BINS];
+            Bin acc;
+            for (int b = BINS - 1; b > 0; b--) {
+                acc.n += bins[b].n;
+                for (int k = 0; k < 3; k++) {
+                    acc.lo[k] = std::min(acc.lo[k], bins[b].lo[k]);
+                    acc.hi[k] = std::max(acc.hi[k], bins[b].hi[k]);
+                }
+                right_n[b] = acc.n;
+                right_area[b] = acc.n ? box_area(acc.lo, acc.hi) : 0.0;
+            }
+            acc = Bin();
+            for (int b = 0; b + 1 < BINS; b++) {  // left = bins [0, b], right = bins (b, BINS)
+                acc.n += bins[b].n;
+                for (int k = 0; k < 3; k++) {
+                    acc.lo[k] = std::min(acc.lo[k], bins[b].lo[k]);
+                    acc.hi[k] = std::max(acc.hi[k], bins[b].hi[k]);
+                }
+                if (acc.n == 0 || right_n[b + 1] == 0) continue;
+                const double cost = box_area(acc.lo, acc.hi) * (double)acc.n + right_area[b + 1] * (double)right_n[b + 1];
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_bin = b;
+                    best_scale = scale;
+                }
+            }
+        }
+        // One more candidate: the largest leaf on its own (a box that spans the others - a medium that
+        // fills the scene - has a central centroid, so no centroid split ever isolates it).
+        {
+            size_t big = lo;
+            double big_area = -1.0;
+            for (size_t i = lo; i < hi; i++) {
+                const double a = box_area(L[i].lo, L[i].hi);
+                if (a > big_area) {
+                    big_area = a;
+                    big = i;
+                }
+            }
+            std::swap(L[lo], L[big]);
+            const SahPart rest = make_part(L, lo + 1, hi);
+            if (big_area + rest.area * (double)(hi - lo - 1) < best_cost) return lo + 1;
+        }
+        if (best_axis < 0) return lo + (hi - lo) / 2;  // all centroids coincide
+        const float origin = cmin[best_axis];
+        auto mid = std::partition(L.begin() + (long)lo, L.begin() + (long)hi, [&](const SahLeaf& l) {
+            return std::min(BINS - 1, (int)((l.c[best_axis] - origin) * best_scale)) <= best_bin;
+        });
+        const size_t m = (size_t)(mid - L.begin());
+        return (m == lo || m == hi) ? lo + (hi - lo) / 2 : m;
+    }
+    static int32_t sah4_node(std::vector<SahLeaf>& L, size_t lo, size_t hi, std::vector<rtd::DNode4>& out, int* need) {
+        std::vector<SahPart> parts{make_part(L, lo, hi)};
+        while (parts.size() < 4) {
+            int pick = -1;
+            for (size_t k = 0; k < parts.size(); k++)
+                if (parts[k].hi - parts[k].lo > 1 && (pick < 0 || parts[k].area > parts[(size_t)pick].area)) pick = (int)k;
+            if (pick < 0) break;
+            const SahPart p = parts[(size_t)pick];
+            const size_t mid = sah_split(L, p.lo, p.hi);
+            parts[(size_t)pick] = make_part(L, p.lo, mid);
+            parts.insert(parts.begin() + pick + 1, make_part(L, mid, p.hi));
+        }
+        // Slot order only matters to rays that enter several children at the same distance - those that
+        // start inside them.  Largest box first: it is the one most of the other lanes of a wave are in.
+        std::stable_sort(parts.begin(), parts.end(), [](const SahPart& a, const SahPart& b) { return a.area > b.area; });
+        const int32_t me = (int32_t)out.size();
+        out.emplace_back();
+        rtd::DNode4 n;
+        std::memset(&n, 0, sizeof(n));
+        int deepest = 0;
+        for (int k = 0; k < 4; k++) {
+            n.child[k] = rtd::RT_EMPTY;
+            if ((size_t)k >= parts.size()) continue;
+            const SahPart& p = parts[(size_t)k];
+            for (int a = 0; a < 3; a++) {
+                n.lo[k][a] = p.blo[a];
+                n.hi[k][a] = p.bhi[a];
+            }
+            int below = 0;
+            n.child[k] = p.hi - p.lo == 1 ? L[p.lo].ref : sah4_node(L, p.lo, p.hi, out, &below);
+            deepest = std::max(deepest, below);
+        }
+        out[(size_t)me] = n;
+        *need = (int)parts.size() - 1 + deepest;
+        return me;
+    }
+    // Super-root like build_nodes4's.  false: the tree has leaves without finite bounds, nothing was added.
+    static bool build_sah4(const rt_scene_desc& d, int32_t root, float pad, std::vector<rtd::DNode4>& out, int32_t* root_out, int* need) {
+        std::vector<SahLeaf> L;
+        if (!collect_leaves(d, root, pad, L)) return false;
+        const int32_t me = (int32_t)out.size();
+        out.emplace_back();
+        rtd::DNode4 n;
+        std::memset(&n, 0, sizeof(n));
+        for (int k = 0; k < 4; k++) n.child[k] = rtd::RT_EMPTY;
+        *need = 0;
+        if (!L.empty()) {
+            const SahPart all = make_part(L, 0, L.size());
+            for (int a = 0; a < 3; a++) {
+                n.lo[0][a] = all.blo[a];
+                n.hi[0][a] = all.bhi[a];
+            }
+            n.child[0] = L.size() == 1 ? L[0].ref : sah4_node(L, 0, L.size(), out, need);
+        }
+        out[(size_t)me] = n;
+        *root_out = me;
+        return true;
     }
 
     // DNode2 super-root for the reference BVH rooted at `root`: child 0 = that root, child 1 empty.

@@ -683,9 +683,17 @@ __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, 
 // world.hit(ray, min, max): the top-level Vec (src/hitting.rs:188-194 -> :88-104) over the
 // world BVH and the unbounded objects; inside the BVH, BVHNode::hit (:211-229).
 enum { WALK_NODE2 = 0, WALK_OWN_BOX_LDS = 1, WALK_SWEEP = 2, WALK_SWEEP_LEAN = 3 /* rect lists and spheres only */,
-       WALK_NODE2_MESH4 = 4 /* WALK_NODE2 with four-wide mesh trees */ };
+       WALK_NODE2_MESH4 = 4 /* four-wide world and mesh trees, every object kind */,
+       // the same walk compiled without the object kinds a scene does not hold (smaller kernels, fewer spills):
+       WALK_NODE4_MESH = 5 /* no media */, WALK_NODE4_MEDIA = 6 /* no meshes */, WALK_NODE4_PLAIN = 7 /* neither */ };
+constexpr bool walks_node4(int mode) { return mode >= WALK_NODE2_MESH4; }
 template <int MODE> struct WalkFeat {
-    static constexpr int value = MODE == WALK_SWEEP_LEAN ? FEAT_SPHERES : MODE == WALK_NODE2_MESH4 ? (FEAT_ALL | FEAT_BLAS4) : FEAT_ALL;
+    static constexpr int value = MODE == WALK_SWEEP_LEAN     ? FEAT_SPHERES
+                                 : MODE == WALK_NODE2_MESH4  ? (FEAT_ALL | FEAT_BLAS4)
+                                 : MODE == WALK_NODE4_MESH   ? ((FEAT_ALL & ~FEAT_MEDIA) | FEAT_BLAS4)
+                                 : MODE == WALK_NODE4_MEDIA  ? (FEAT_ALL & ~FEAT_BLAS)
+                                 : MODE == WALK_NODE4_PLAIN  ? (FEAT_ALL & ~FEAT_BLAS & ~FEAT_MEDIA)
+                                                             : FEAT_ALL;
 };
 
 template <typename T, int MODE, typename ST>
@@ -777,7 +785,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
             T bound = max_dist;
             float bound32 = round_up(bound);
             int sp = 0;
-            int32_t next = MODE == WALK_NODE2_MESH4 ? S.tlas_root4 : S.tlas_root;
+            int32_t next = walks_node4(MODE) ? S.tlas_root4 : S.tlas_root;
             int32_t best_rank = -1;
             for (;;) {  // one step per iteration: one leaf (exact object test) or one node (two box tests)
                 if (next == RT_EMPTY) {
@@ -802,7 +810,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                         }
                     }
                     next = RT_EMPTY;
-                } else if constexpr (MODE == WALK_NODE2_MESH4) {  // four-wide step, as in blas_hit4
+                } else if constexpr (walks_node4(MODE)) {  // four-wide step, as in blas_hit4
                     const float MISS = __int_as_float(0x7f800000);
                     const Node4Regs n = load_node4(S.nodes4, next);
                     float k0, k1, k2, k3, e;
@@ -974,12 +982,12 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
 
 // ------------------------------------------------------------------ kernels
 constexpr int BLOCK = 256;
-template <int MODE> struct StackFor {
+template <int MODE, bool DEEP = walks_node4(MODE)> struct StackFor {
     typedef Stack type;
     static constexpr int SPILL = 1;
     static __device__ __forceinline__ Stack make(int32_t* lds, int, int32_t*) { return Stack{lds, BLOCK}; }
 };
-template <> struct StackFor<WALK_NODE2_MESH4> {
+template <int MODE> struct StackFor<MODE, true> {
     typedef DeepStack type;
     static constexpr int SPILL = RT_STACK_OVERFLOW;
     static __device__ __forceinline__ DeepStack make(int32_t* lds, int cap, int32_t* spill) { return DeepStack{lds, BLOCK, cap, spill}; }
@@ -1526,12 +1534,21 @@ void Launch<T>::extend(const DScene<T>& S, const DSmallScene& small, const DBatc
         hipLaunchKernelGGL((k_extend<T, 64, WALK_SWEEP>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (small.blob && stack <= 16)
         hipLaunchKernelGGL((k_extend<T, 16, WALK_OWN_BOX_LDS>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
-    else if (S.nodes4 && stack <= 16)
-        hipLaunchKernelGGL((k_extend<T, 16, WALK_NODE2_MESH4>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
-    else if (S.nodes4 && stack <= 32)
-        hipLaunchKernelGGL((k_extend<T, 32, WALK_NODE2_MESH4>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
-    else if (S.nodes4)
-        hipLaunchKernelGGL((k_extend<T, 64, WALK_NODE2_MESH4>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+#define RT_EXTEND(STACK, MODE)                                                                                           \
+    hipLaunchKernelGGL((k_extend<T, STACK, MODE>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, \
+                       tile_offsets, n_tiles)
+#define RT_EXTEND4(MODE)                       \
+    do {                                       \
+        if (stack <= 16) RT_EXTEND(16, MODE);  \
+        else if (stack <= 32) RT_EXTEND(32, MODE); \
+        else RT_EXTEND(64, MODE);              \
+    } while (0)
+    else if (S.nodes4 && S.has_meshes && S.has_media) RT_EXTEND4(WALK_NODE2_MESH4);
+    else if (S.nodes4 && S.has_meshes) RT_EXTEND4(WALK_NODE4_MESH);
+    else if (S.nodes4 && S.has_media) RT_EXTEND4(WALK_NODE4_MEDIA);
+    else if (S.nodes4) RT_EXTEND4(WALK_NODE4_PLAIN);
+#undef RT_EXTEND4
+#undef RT_EXTEND
     else if (stack <= 16)
         hipLaunchKernelGGL((k_extend<T, 16, WALK_NODE2>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (stack <= 32)
@@ -1551,9 +1568,17 @@ void Launch<T>::bounce(const DScene<T>& S, const DSmallScene& small, const DBatc
     else if (S.n_sweep > 0 && stack <= 16) RT_BOUNCE(16, WALK_SWEEP);
     else if (S.n_sweep > 0) RT_BOUNCE(64, WALK_SWEEP);
     else if (small.blob && stack <= 16) RT_BOUNCE(16, WALK_OWN_BOX_LDS);
-    else if (S.nodes4 && stack <= 16) RT_BOUNCE(16, WALK_NODE2_MESH4);
-    else if (S.nodes4 && stack <= 32) RT_BOUNCE(32, WALK_NODE2_MESH4);
-    else if (S.nodes4) RT_BOUNCE(64, WALK_NODE2_MESH4);
+#define RT_BOUNCE4(MODE)                       \
+    do {                                       \
+        if (stack <= 16) RT_BOUNCE(16, MODE);  \
+        else if (stack <= 32) RT_BOUNCE(32, MODE); \
+        else RT_BOUNCE(64, MODE);              \
+    } while (0)
+    else if (S.nodes4 && S.has_meshes && S.has_media) RT_BOUNCE4(WALK_NODE2_MESH4);
+    else if (S.nodes4 && S.has_meshes) RT_BOUNCE4(WALK_NODE4_MESH);
+    else if (S.nodes4 && S.has_media) RT_BOUNCE4(WALK_NODE4_MEDIA);
+    else if (S.nodes4) RT_BOUNCE4(WALK_NODE4_PLAIN);
+#undef RT_BOUNCE4
     else if (stack <= 16) RT_BOUNCE(16, WALK_NODE2);
     else if (stack <= 32) RT_BOUNCE(32, WALK_NODE2);
     else RT_BOUNCE(64, WALK_NODE2);

@@ -133,7 +133,8 @@ struct DScene {
     int32_t needs_uv;  // some material reads (u, v): image textures, checkers
     int32_t tlas_root4;  // world BVH in nodes4 (valid when nodes4 != nullptr)
     int32_t stack_cap;   // > 0: entries of the LDS stack a four-wide walk may use before it overflows (tests)
-    int32_t pad_[3];
+    int32_t has_meshes, has_media;  // object kinds present: pick the four-wide kernel compiled for them
+    int32_t pad_[1];
     DCamera<T> camera;
     DSky<T> sky;
 };

@@ -274,7 +274,12 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_ORDERED": "0"}),
         ("knight", {"RT_BVH4": "0"}),                          # binary instead of four-wide mesh tree
         ("knight", {"RT_BVH4": "0", "RT_ORDERED": "0"}),
-        ("knight", {"RT_STACK_CAP": "6"}),                     # four-wide walk mostly on the private overflow stack
+        ("knight", {"RT_SAH": "0"}),                           # the reference's grouping (folded) instead of SAH trees
+        ("blocks_ball", {"RT_SAH": "0"}),
+        ("knight", {"RT_SAH": "0", "RT_ORDERED": "0"}),
+        ("knight", {"RT_FEATURES": "all"}),                     # the general four-wide kernel instead of the one without media
+        ("blocks_ball", {"RT_FEATURES": "all"}),                # ... instead of the one without meshes
+        ("knight", {"RT_STACK_CAP": "6"}),                   # four-wide walk mostly on the private overflow stack
         ("blocks_ball", {"RT_STACK_CAP": "3"}),
         ("globe", {"RT_SWEEP_MAX": "0", "RT_FUSE": "0"}),
         ("cornell", {"RT_TAIL": "0"}),                         # a launch per bounce to the end, no tail launch
