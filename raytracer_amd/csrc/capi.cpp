@@ -320,8 +320,8 @@ struct Engine : EngineBase {
                     if (std::getenv("RT_DEBUG") && v[(size_t)S.tlas_root4].child[0] >= 0) {
                         const rtd::DNode4& w = v[(size_t)v[(size_t)S.tlas_root4].child[0]];
                         for (int k = 0; k < 4; k++)
-                            std::fprintf(stderr, "  world slot %d: child %d  [%g %g %g] - [%g %g %g]\n", k, w.child[k], w.lo[k][0], w.lo[k][1],
-                                         w.lo[k][2], w.hi[k][0], w.hi[k][1], w.hi[k][2]);
+                            std::fprintf(stderr, "  world slot %d: child %d  [%g %g %g] - [%g %g %g]\n", k, w.child[k], w.lo[0][k], w.lo[1][k],
+                                         w.lo[2][k], w.hi[0][k], w.hi[1][k], w.hi[2][k]);
                     }
                     nodes4.upload(v);
                     S.nodes4 = nodes4.p;
@@ -643,7 +643,9 @@ struct Engine : EngineBase {
         for (int k = 0; k < 4; k++) {
             n.child[k] = rtd::RT_EMPTY;
             if ((size_t)k >= slots.size()) continue;
-            padded_box(d.nodes[slots[(size_t)k]], pad, n.lo[k], n.hi[k]);
+            float blo[3], bhi[3];
+            padded_box(d.nodes[slots[(size_t)k]], pad, blo, bhi);
+            n.set_box(k, blo, bhi);
             int below = 0;
             n.child[k] = node4_child(d, slots[(size_t)k], pad, out, &below);
             if (n.child[k] != rtd::RT_EMPTY) live++;
@@ -659,7 +661,9 @@ struct Engine : EngineBase {
         rtd::DNode4 n;
         std::memset(&n, 0, sizeof(n));
         for (int k = 0; k < 4; k++) n.child[k] = rtd::RT_EMPTY;
-        padded_box(d.nodes[root], pad, n.lo[0], n.hi[0]);
+        float blo[3], bhi[3];
+        padded_box(d.nodes[root], pad, blo, bhi);
+        n.set_box(0, blo, bhi);
         n.child[0] = node4_child(d, root, pad, out, need);
         out[(size_t)me] = n;
         return me;
@@ -827,10 +831,7 @@ struct Engine : EngineBase {
             n.child[k] = rtd::RT_EMPTY;
             if ((size_t)k >= parts.size()) continue;
             const SahPart& p = parts[(size_t)k];
-            for (int a = 0; a < 3; a++) {
-                n.lo[k][a] = p.blo[a];
-                n.hi[k][a] = p.bhi[a];
-            }
+            n.set_box(k, p.blo, p.bhi);
             int below = 0;
             n.child[k] = p.hi - p.lo == 1 ? L[p.lo].ref : sah4_node(L, p.lo, p.hi, out, &below);
             deepest = std::max(deepest, below);
@@ -851,10 +852,7 @@ struct Engine : EngineBase {
         *need = 0;
         if (!L.empty()) {
             const SahPart all = make_part(L, 0, L.size());
-            for (int a = 0; a < 3; a++) {
-                n.lo[0][a] = all.blo[a];
-                n.hi[0][a] = all.bhi[a];
-            }
+            n.set_box(0, all.blo, all.bhi);
             n.child[0] = L.size() == 1 ? L[0].ref : sah4_node(L, 0, L.size(), out, need);
         }
         out[(size_t)me] = n;

@@ -417,6 +417,8 @@ struct Stack {
     int stride;
     __device__ __forceinline__ void put(int e, int32_t v) { base[e * stride] = v; }
     __device__ __forceinline__ int32_t get(int e) const { return base[e * stride]; }
+    __device__ __forceinline__ bool room(int, int) const { return false; }  // (depth unknown here: checked stores only)
+    __device__ __forceinline__ void put_near(int e, int32_t v) { base[e * stride] = v; }
 };
 // The same with a private array behind it for entries beyond `cap`: a four-wide walk keeps up to 3
 // siblings per level on the stack, which in its worst visiting order is more than the LDS part holds.
@@ -430,6 +432,8 @@ struct DeepStack {
         else overflow[e - cap] = v;
     }
     __device__ __forceinline__ int32_t get(int e) const { return e < cap ? base[e * stride] : overflow[e - cap]; }
+    __device__ __forceinline__ bool room(int e, int n) const { return e + n <= cap; }  // entries e .. e+n-1 are in LDS
+    __device__ __forceinline__ void put_near(int e, int32_t v) { base[e * stride] = v; }
 };
 
 // BVHNode::hit over a triangle BVH (src/hitting.rs:211-229).  The reference's recursion "left with
@@ -496,17 +500,17 @@ __device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_di
     return found;
 }
 
-struct alignas(16) Node4Regs {  // a DNode4 fetched as eight 16-byte loads
-    uint4 q[8];
-    __device__ __forceinline__ const float* lo(int c) const { return (const float*)q + 3 * c; }
-    __device__ __forceinline__ const float* hi(int c) const { return (const float*)q + 12 + 3 * c; }
-    __device__ __forceinline__ int32_t child(int c) const { return ((const int32_t*)q)[24 + c]; }
+struct alignas(16) Node4Regs {  // a DNode4 fetched as seven 16-byte loads (the padding stays behind)
+    uint4 q[7];
+    __device__ __forceinline__ const float* lo(int axis) const { return (const float*)&q[axis]; }
+    __device__ __forceinline__ const float* hi(int axis) const { return (const float*)&q[3 + axis]; }
+    __device__ __forceinline__ int32_t child(int c) const { return ((const int32_t*)&q[6])[c]; }
 };
 __device__ __forceinline__ Node4Regs load_node4(const DNode4* nodes, int idx) {
     const uint4* p = (const uint4*)(nodes + idx);
     Node4Regs n;
 #pragma unroll
-    for (int k = 0; k < 8; k++) n.q[k] = p[k];
+    for (int k = 0; k < 7; k++) n.q[k] = p[k];
     return n;
 }
 __device__ __forceinline__ void order2(float& ka, int32_t& ca, float& kb, int32_t& cb) {  // compare-exchange
@@ -514,6 +518,77 @@ __device__ __forceinline__ void order2(float& ka, int32_t& ca, float& kb, int32_
     const float k0 = swap ? kb : ka, k1 = swap ? ka : kb;
     const int32_t c0 = swap ? cb : ca, c1 = swap ? ca : cb;
     ka = k0; kb = k1; ca = c0; cb = c1;
+}
+
+#if defined(RT_EXP) && (RT_EXP & 32)  // measurement only: lane / wave step counts of the four-wide walks (scripts/exp_steps.py)
+__device__ unsigned long long g_prof[8];
+#define RT_PROF_DECL uint32_t prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define RT_PROF(k) do { prof_[k]++; if ((__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) prof_[(k) + 1]++; } while (0)
+#define RT_PROF_FLUSH do { for (int k_ = 0; k_ < 8; k_++) if (prof_[k_]) atomicAdd(&g_prof[k_], (unsigned long long)prof_[k_]); } while (0)
+extern "C" void rt_exp_prof(unsigned long long* out, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+    }
+}
+#else
+#define RT_PROF_DECL
+#define RT_PROF(k)
+#define RT_PROF_FLUSH
+#endif
+
+// One step of a four-wide walk: the four child boxes of `n` against the ray (the arithmetic of
+// box2_hit, operation for operation, without branches: one plane of all four children per pair of
+// packed operations), the children that are hit ordered nearest first (or left to right), all but
+// the first pushed - farthest first - and the first returned (RT_EMPTY: none was hit).
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <typename ST>
+__device__ __forceinline__ int32_t node4_step(const Node4Regs& n, const RayF& f, float tmin32, float bound32, bool ordered,
+                                              ST& st, int& sp) {
+    const float MISS = __int_as_float(0x7f800000);
+    float near[4] = {tmin32, tmin32, tmin32, tmin32};
+    float far[4] = {bound32, bound32, bound32, bound32};
+    const float o[3] = {f.ox, f.oy, f.oz}, inv[3] = {f.ix, f.iy, f.iz};
+#pragma unroll
+    for (int axis = 0; axis < 3; axis++) {
+        const float2v o2 = {o[axis], o[axis]}, i2 = {inv[axis], inv[axis]};
+        const float* lo = n.lo(axis);
+        const float* hi = n.hi(axis);
+#pragma unroll
+        for (int pair = 0; pair < 2; pair++) {
+            const float2v lo2 = {lo[2 * pair], lo[2 * pair + 1]}, hi2 = {hi[2 * pair], hi[2 * pair + 1]};
+            const float2v ta = (lo2 - o2) * i2, tb = (hi2 - o2) * i2;
+            near[2 * pair] = fmaxf(fminf(ta.x, tb.x), near[2 * pair]);
+            far[2 * pair] = fminf(fmaxf(ta.x, tb.x), far[2 * pair]);
+            near[2 * pair + 1] = fmaxf(fminf(ta.y, tb.y), near[2 * pair + 1]);
+            far[2 * pair + 1] = fminf(fmaxf(ta.y, tb.y), far[2 * pair + 1]);
+        }
+    }
+    int32_t c0 = n.child(0), c1 = n.child(1), c2 = n.child(2), c3 = n.child(3);
+    float k0 = ((c0 != RT_EMPTY) & (far[0] >= near[0])) ? (ordered ? near[0] : 0.0f) : MISS;
+    float k1 = ((c1 != RT_EMPTY) & (far[1] >= near[1])) ? (ordered ? near[1] : 1.0f) : MISS;
+    float k2 = ((c2 != RT_EMPTY) & (far[2] >= near[2])) ? (ordered ? near[2] : 2.0f) : MISS;
+    float k3 = ((c3 != RT_EMPTY) & (far[3] >= near[3])) ? (ordered ? near[3] : 3.0f) : MISS;
+    order2(k0, c0, k1, c1);
+    order2(k2, c2, k3, c3);
+    order2(k0, c0, k2, c2);
+    order2(k1, c1, k3, c3);
+    order2(k1, c1, k2, c2);
+    if (st.room(sp, 3)) {  // the usual case: three stores, the stack pointer moves past those that count
+        st.put_near(sp, c3);
+        sp += k3 < MISS;
+        st.put_near(sp, c2);
+        sp += k2 < MISS;
+        st.put_near(sp, c1);
+        sp += k1 < MISS;
+    } else {
+        if (k3 < MISS) st.put(sp++, c3);
+        if (k2 < MISS) st.put(sp++, c2);
+        if (k1 < MISS) st.put(sp++, c1);
+    }
+    return k0 < MISS ? c0 : RT_EMPTY;
 }
 
 // The same walk as blas_hit over the four-wide tree: one 128-byte fetch decides two levels of the
@@ -525,40 +600,26 @@ __device__ bool blas_hit4(const DScene<T>& S, const Ray<T>& r, int root, T min_d
     const RayF f = ray_f32(r);
     const float tmin32 = round_down(min_dist);
     float bound32 = round_up(max_dist);
-    const float MISS = __int_as_float(0x7f800000);
     int sp = sp0;
     int32_t next = root;
     bool found = false;
     int32_t best_rank = -1;
+    RT_PROF_DECL;
     for (;;) {
+        RT_PROF(0);
         const Node4Regs n = load_node4(S.nodes4, next);
-        float k0, k1, k2, k3;
-        int32_t c0 = n.child(0), c1 = n.child(1), c2 = n.child(2), c3 = n.child(3);
-        {
-            float e;
-            k0 = (c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32, &e)) ? (S.ordered ? e : 0.0f) : MISS;
-            k1 = (c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32, &e)) ? (S.ordered ? e : 1.0f) : MISS;
-            k2 = (c2 != RT_EMPTY && box2_hit(n.lo(2), n.hi(2), f, tmin32, bound32, &e)) ? (S.ordered ? e : 2.0f) : MISS;
-            k3 = (c3 != RT_EMPTY && box2_hit(n.lo(3), n.hi(3), f, tmin32, bound32, &e)) ? (S.ordered ? e : 3.0f) : MISS;
-        }
-        order2(k0, c0, k1, c1);
-        order2(k2, c2, k3, c3);
-        order2(k0, c0, k2, c2);
-        order2(k1, c1, k3, c3);
-        order2(k1, c1, k2, c2);
-        if (k3 < MISS) st.put(sp++, c3);
-        if (k2 < MISS) st.put(sp++, c2);
-        if (k1 < MISS) st.put(sp++, c1);
-        next = k0 < MISS ? c0 : RT_EMPTY;
+        next = node4_step(n, f, tmin32, bound32, S.ordered != 0, st, sp);
         for (;;) {
             if (next == RT_EMPTY) {
                 if (sp == sp0) {
                     *t_out = max_dist;
+                    RT_PROF_FLUSH;
                     return found;
                 }
                 next = st.get(--sp);
             }
             if (next >= 0) break;
+            RT_PROF(2);
             const int tri = -1 - next;  // leaf: the exact test, against the current bound (t == bound passes)
             T t;
             const DTriangle<T> tr = S.triangles[tri];
@@ -787,12 +848,14 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
             int sp = 0;
             int32_t next = walks_node4(MODE) ? S.tlas_root4 : S.tlas_root;
             int32_t best_rank = -1;
+            RT_PROF_DECL;
             for (;;) {  // one step per iteration: one leaf (exact object test) or one node (two box tests)
                 if (next == RT_EMPTY) {
                     if (sp == 0) break;
                     next = st.get(--sp);
                 }
                 if (next < 0) {
+                    RT_PROF(4);
                     const int oi = -1 - next;
                     T th;
                     int prim;
@@ -811,23 +874,9 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                     }
                     next = RT_EMPTY;
                 } else if constexpr (walks_node4(MODE)) {  // four-wide step, as in blas_hit4
-                    const float MISS = __int_as_float(0x7f800000);
+                    RT_PROF(6);
                     const Node4Regs n = load_node4(S.nodes4, next);
-                    float k0, k1, k2, k3, e;
-                    int32_t c0 = n.child(0), c1 = n.child(1), c2 = n.child(2), c3 = n.child(3);
-                    k0 = (c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32, &e)) ? (S.ordered ? e : 0.0f) : MISS;
-                    k1 = (c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32, &e)) ? (S.ordered ? e : 1.0f) : MISS;
-                    k2 = (c2 != RT_EMPTY && box2_hit(n.lo(2), n.hi(2), f, tmin32, bound32, &e)) ? (S.ordered ? e : 2.0f) : MISS;
-                    k3 = (c3 != RT_EMPTY && box2_hit(n.lo(3), n.hi(3), f, tmin32, bound32, &e)) ? (S.ordered ? e : 3.0f) : MISS;
-                    order2(k0, c0, k1, c1);
-                    order2(k2, c2, k3, c3);
-                    order2(k0, c0, k2, c2);
-                    order2(k1, c1, k3, c3);
-                    order2(k1, c1, k2, c2);
-                    if (k3 < MISS) st.put(sp++, c3);
-                    if (k2 < MISS) st.put(sp++, c2);
-                    if (k1 < MISS) st.put(sp++, c1);
-                    next = k0 < MISS ? c0 : RT_EMPTY;
+                    next = node4_step(n, f, tmin32, bound32, S.ordered != 0, st, sp);
                 } else {
                     const Node2Regs n = load_node2(S.nodes2, next);
                     const int32_t c0 = n.child(0), c1 = n.child(1);
@@ -846,6 +895,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                     }
                 }
             }
+            RT_PROF_FLUSH;
             t = bound;
         }
         if (found && (!have || t < best_t)) {

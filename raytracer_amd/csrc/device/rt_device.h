@@ -26,13 +26,21 @@ struct alignas(16) DNode2 {
 };
 static constexpr int32_t RT_EMPTY = (int32_t)0x80000000;
 
-// Four-wide traversal node for triangle meshes (128 B): the reference's binary tree with every
-// other level folded away, so a walk takes about half as many dependent fetches.  Children keep
-// the reference's left-to-right order; child references as in DNode2.
+// Four-wide traversal node (128 B): the reference's binary tree with every other level folded away
+// (or regrouped by SAH), so a walk takes about half as many dependent fetches.  Child references as
+// in DNode2.  Bounds are stored per axis across the four slots (lo[axis][slot]): seven aligned
+// 16-byte loads bring in a node, and one plane of all four children is tested with one pair of
+// packed operations.
 struct alignas(16) DNode4 {
-    float lo[4][3], hi[4][3];
+    float lo[3][4], hi[3][4];
     int32_t child[4];
     int32_t pad[4];
+    void set_box(int slot, const float* blo, const float* bhi) {
+        for (int a = 0; a < 3; a++) {
+            lo[a][slot] = blo[a];
+            hi[a][slot] = bhi[a];
+        }
+    }
 };
 
 template <typename T>
