@@ -992,6 +992,23 @@ struct Engine : EngineBase {
         }
         return h;
     }
+    // k_extend.  World trees whose leaves are whole objects (no meshes) go to k_extend_refill: node steps
+    // and object tests in separate phases, rays handed out from a launch-wide cursor (counts[1], zeroed
+    // here).  RT_REFILL=n: 0 = k_extend for every scene; n < 64 = lanes also take new rays while others of
+    // their wave still walk, as soon as n lanes wait (measured: slower).
+    void launch_extend(const rtd::DBatch& B, rtd::DQueue<T> q, rtd::DHits<T> h, const T* tmin, const T* tmax, uint32_t depth,
+                       uint32_t n_tiles, int grid) {
+        int refill = 0;
+        if (S.nodes4 && S.n_sweep == 0 && !small.blob) {
+            refill = S.has_meshes ? 0 : 64;
+            if (const char* e = std::getenv("RT_REFILL")) refill = (int)std::strtol(e, nullptr, 10);
+        }
+        if (refill > 0) {
+            HIP_CHECK(hipMemsetAsync(counts.p + 1, 0, sizeof(uint32_t), stream));
+            grid = std::min(grid, num_cus * 4);
+        }
+        rtd::Launch<T>::extend(S, small, B, q, h, tmin, tmax, depth, tile_offsets.p, n_tiles, stack_depth, grid, counts.p + 1, refill, stream);
+    }
     static uint32_t tiles_for(size_t n) { return (uint32_t)((n + RT_TILE - 1) / RT_TILE); }
     int grid_for(size_t n) {  // persistent blocks, grid-stride over the dense work index
         size_t blocks = (n + 255) / 256;
@@ -1019,7 +1036,7 @@ struct Engine : EngineBase {
             T* tmax = tminmax.p + capacity;
             rtd::Launch<T>::load_rays(io_f64.p, (uint32_t)m, q, tmin, tmax, tile_counts[0].p, stream);
             rtd::launch_scan_tiles(tile_counts[0].p, tiles_for(m), tile_offsets.p, nullptr, counts.p, nullptr, stream);
-            rtd::Launch<T>::extend(S, small, B, q, h, tmin, tmax, 0, tile_offsets.p, tiles_for(m), stack_depth, grid_for(m), stream);
+            launch_extend(B, q, h, tmin, tmax, 0, tiles_for(m), grid_for(m));
             rtd::Launch<T>::store_hits(q, h, (uint32_t)m, io_hits.p, stream);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipMemcpyAsync(out + base, io_hits.p, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
@@ -1106,8 +1123,7 @@ struct Engine : EngineBase {
                                            tile_offsets.p, tile_counts[out].p, n_tiles, stack_depth, grid, nullptr, stream);
                     if (timing) HIP_CHECK(hipEventRecord(event(ev + 1), stream));
                 } else {
-                    rtd::Launch<T>::extend(S, small, B, queue(in), hits(false), nullptr, nullptr, depth, tile_offsets.p,
-                                           n_tiles, stack_depth, grid, stream);
+                    launch_extend(B, queue(in), hits(false), nullptr, nullptr, depth, n_tiles, grid);
                     if (timing) {
                         HIP_CHECK(hipEventRecord(event(ev + 1), stream));
                         spans.push_back({ev + 1, 1});

@@ -1204,6 +1204,237 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
     }
 }
 
+// ---- k_extend for the four-wide trees with lane refill.
+// A wave of k_extend is as slow as its slowest ray: on the knight the lanes of a wave are 30 %
+// (node steps) and 6 % (triangle tests) busy.  Here a wave keeps walking while lanes whose ray is
+// done wait; when REFILL lanes are waiting (or nobody walks any more) they write their hit records
+// and take the next rays of the queue (one atomic per refill on a launch-wide cursor).  For that
+// the walk is one flat loop - a step is a node, a world leaf or a triangle, at whichever level the
+// lane is - instead of closest_hit's nested loops; the arithmetic and the tie rules are the same.
+template <typename T, int MODE, typename ST>
+struct Walk4 {
+    static constexpr int FEAT = WalkFeat<MODE>::value;
+    // meshes met in the world tree are walked by step() itself; the object test only needs them for media boundaries
+    static constexpr int LEAF_FEAT = (FEAT & FEAT_MEDIA) ? FEAT : (FEAT & ~(FEAT_BLAS | FEAT_BLAS4));
+    Ray<T> ray;   // the query, world space
+    T min_dist;
+    T bound;      // world level: nearest hit so far (or the query's upper bound)
+    Winner w;
+    int32_t best_rank;
+    bool found;
+    RayF f;       // current level
+    float tmin32, bound32;
+    int sp;
+    int32_t next;
+    bool in_mesh;  // mesh level (between a BLAS leaf of the world tree and the emptying of its part of the stack)
+    int m_sp0, m_oi, m_prim;
+    int32_t m_rank;
+    bool m_found;
+    Ray<T> mr;
+    T m_bound;
+
+    __device__ __forceinline__ void begin(const DScene<T>& S, const Ray<T>& r, T lo, T hi) {
+        ray = r;
+        min_dist = lo;
+        bound = hi;
+        w = Winner{-1, -1};
+        best_rank = -1;
+        found = false;
+        f = ray_f32(r);
+        tmin32 = round_down(lo);
+        bound32 = round_up(hi);
+        sp = 0;
+        next = S.tlas_root4;
+        in_mesh = false;
+        m_sp0 = 0; m_oi = -1; m_prim = -1; m_rank = -1; m_found = false;
+        mr = r;
+        m_bound = hi;
+    }
+    // next is empty: takes the next entry off the stack (leaving a finished mesh on the way); false when
+    // the walk is over (found / bound / w hold the answer of the world BVH).
+    __device__ __forceinline__ bool pop(const DScene<T>& S, ST& st) {
+        if (in_mesh && sp == m_sp0) {  // the mesh is done: its nearest triangle is this leaf's answer
+            in_mesh = false;
+            if (m_found) {
+                const int32_t rank = S.objects[m_oi].dfs_rank;
+                if (!found || m_bound < bound || rank > best_rank) {
+                    bound = m_bound;
+                    w = Winner{m_oi, m_prim};
+                    best_rank = rank;
+                    found = true;
+                }
+            }
+            f = ray_f32(ray);
+            bound32 = round_up(bound);
+        }
+        if (sp == 0) return false;
+        next = st.get(--sp);
+        return true;
+    }
+    __device__ __forceinline__ void node(const DScene<T>& S, ST& st) {  // next >= 0
+        const Node4Regs n = load_node4(S.nodes4, next);
+        next = node4_step(n, f, tmin32, bound32, S.ordered != 0, st, sp);
+    }
+    __device__ __forceinline__ void leaf(const DScene<T>& S, ST& st, PathRef path, uint32_t depth) {  // next < 0, not empty
+        if (in_mesh) {
+            const int tri = -1 - next;  // the exact test, against the mesh's current bound (t == bound passes)
+            T t;
+            const DTriangle<T> tr = S.triangles[tri];
+            if (triangle_hit(tr, mr, min_dist, m_bound, &t)) {
+                if (!m_found || t < m_bound || tr.dfs_rank > m_rank) {
+                    m_bound = t;
+                    bound32 = round_up(t);
+                    m_prim = tri;
+                    m_rank = tr.dfs_rank;
+                    m_found = true;
+                }
+            }
+            next = RT_EMPTY;
+        } else {
+            const int oi = -1 - next;
+            const DObject ob = S.objects[oi];
+            if ((FEAT & FEAT_BLAS) != 0 && ob.kind == RT_OBJ_BLAS) {  // enter the mesh (simple_object_hit's BLAS case)
+                mr = ray;
+                if (ob.xform >= 0) mr = to_object_space(S.xforms[ob.xform], ray);
+                f = ray_f32(mr);
+                in_mesh = true;
+                m_sp0 = sp;
+                m_oi = oi;
+                m_bound = bound;
+                m_found = false;
+                m_rank = -1;
+                next = ob.first4;
+            } else {
+                T th;
+                int prim;
+                if (object_hit<T, false, LEAF_FEAT>(S, oi, ray, min_dist, bound, st, sp, path, depth, &th, &prim)) {
+                    if (!found || th < bound || ob.dfs_rank > best_rank) {
+                        bound = th;
+                        bound32 = round_up(th);
+                        w = Winner{oi, prim};
+                        best_rank = ob.dfs_rank;
+                        found = true;
+                    }
+                }
+                next = RT_EMPTY;
+            }
+        }
+    }
+};
+
+template <typename T, int STACK, int MODE>
+__global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend_refill(DScene<T> S, DBatch B, DQueue<T> q, DHits<T> h, const T* tmin_arr,
+                                                                         const T* tmax_arr, uint32_t depth,
+                                                                         const uint32_t* __restrict__ tile_offsets, uint32_t n_tiles,
+                                                                         uint32_t* __restrict__ cursor, uint32_t refill) {
+    static_assert(walks_node4(MODE), "four-wide trees only");
+    constexpr int FEAT = WalkFeat<MODE>::value;
+    __shared__ int32_t lds_stack[STACK * BLOCK];
+    int32_t stack_spill[StackFor<MODE>::SPILL];
+    typedef typename StackFor<MODE>::type ST;
+    ST st = StackFor<MODE>::make(lds_stack + threadIdx.x, S.stack_cap > 0 && S.stack_cap < STACK ? S.stack_cap : STACK, stack_spill);
+    const uint32_t total = tile_offsets[n_tiles];
+    const uint32_t lane = threadIdx.x & 63;
+    enum { IDLE = 0, WALK = 1, DONE = 2 };
+    int state = IDLE;
+    bool exhausted = false;  // (wave-uniform)
+    uint32_t slot = 0, pid = 0;
+    // rays a wave takes from the queue at a time: a quarter of its even share, so that the waves end together,
+    // within [64, 2048] (an atomic on the launch-wide cursor per share)
+    const uint32_t CHUNK = max(64u, min(2048u, (total / (gridDim.x * (BLOCK / 64) * 4u)) & ~63u));
+    uint32_t chunk_lo = 0, chunk_hi = 0;                                // (wave-uniform) what is left of the wave's share
+    Walk4<T, MODE, ST> walk;
+    for (;;) {
+        const uint64_t walking = __ballot(state == WALK);
+        if (walking == 0 || (uint32_t)__popcll(__ballot(state == DONE)) >= refill) {
+            if (state == DONE) {
+                // the rest of world.hit: the unbounded objects of the top-level list, in its order (src/hitting.rs:88-104)
+                const PathRef path{&B, pid};
+                const T max_dist = tmax_arr ? tmax_arr[slot] : Lim<T>::inf();
+                bool have = false;
+                T best_t = 0;
+                Winner best{-1, -1};
+                for (int e = 0; e < S.n_top; e++) {
+                    const int entry = S.top_list[e];
+                    bool found_here;
+                    T t = 0;
+                    Winner w{-1, -1};
+                    if (entry != RT_TOP_BVH) {
+                        found_here = object_hit<T, false, FEAT>(S, entry, walk.ray, walk.min_dist, max_dist, st, 0, path, depth, &t, &w.prim);
+                        w.obj = entry;
+                    } else {
+                        found_here = walk.found;
+                        t = walk.bound;
+                        w = walk.w;
+                    }
+                    if (found_here && (!have || t < best_t)) {
+                        best_t = t;
+                        best = w;
+                        have = true;
+                    }
+                }
+                const uint32_t i = slot;
+                if (have) {
+                    Surface<T> sf = make_surface<T, FEAT>(S, walk.ray, best_t, best, S.needs_uv != 0 || h.owner != nullptr);
+                    h.t[i] = best_t;
+                    h.nx[i] = sf.normal.x; h.ny[i] = sf.normal.y; h.nz[i] = sf.normal.z;
+                    h.u[i] = sf.u; h.v[i] = sf.v;
+                    h.mat_front[i] = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
+                    if (h.owner) {
+                        h.owner[i] = sf.owner;
+                        h.sub[i] = sf.sub;
+                        h.world_index[i] = S.objects[best.obj].world_index;
+                    }
+                } else {
+                    h.mat_front[i] = RT_MISS;
+                }
+                state = IDLE;
+            }
+            while (!exhausted) {
+                const uint64_t idle = __ballot(state == IDLE);
+                if (idle == 0) break;
+                if (chunk_lo >= chunk_hi) {
+                    // the wave's share of the queue has run out: a new one (one atomic per CHUNK rays - every
+                    // wave of the launch shares the cursor, and atomics on one address are served one by one)
+                    uint32_t fresh = 0;
+                    if (lane == 0) fresh = atomicAdd(cursor, CHUNK);
+                    fresh = (uint32_t)__shfl((int)fresh, 0);
+                    if (fresh >= total) {
+                        exhausted = true;
+                        break;
+                    }
+                    chunk_lo = fresh;
+                    chunk_hi = min(fresh + CHUNK, total);
+                }
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t avail = chunk_hi - chunk_lo;
+                if (state == IDLE && rank < avail) {
+                    uint32_t tile;
+                    slot = slot_of(tile_offsets, n_tiles, chunk_lo + rank, chunk_lo, &tile);
+                    const Ray<T> r = load_ray(q, slot);
+                    pid = q.pid[slot];
+                    walk.begin(S, r, tmin_arr ? tmin_arr[slot] : (T)0.001, tmax_arr ? tmax_arr[slot] : Lim<T>::inf());
+                    state = WALK;
+                }
+                chunk_lo += min((uint32_t)__popcll(idle), avail);
+            }
+            if (__ballot(state == WALK) == 0) break;
+        }
+        if (state == WALK) {
+            // node steps until this lane holds a leaf (or is through); then the leaves of all lanes together
+            for (;;) {
+                if (walk.next == RT_EMPTY && !walk.pop(S, st)) {
+                    state = DONE;
+                    break;
+                }
+                if (walk.next < 0) break;
+                walk.node(S, st);
+            }
+        }
+        if (state == WALK) walk.leaf(S, st, PathRef{&B, pid}, depth);
+    }
+}
+
 // Texture::value: SolidColour (src/textures.rs:18-21) / ImageTexture (:39-52).
 template <typename T>
 __device__ __forceinline__ V3<T> texture_value(const DScene<T>& S, const DMaterial<T>& m, T u, T v) {
@@ -1575,7 +1806,7 @@ void Launch<T>::raygen(const DScene<T>& S, const DBatch& B, DQueue<T> q, uint32_
 template <typename T>
 void Launch<T>::extend(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
                        uint32_t depth, const uint32_t* tile_offsets, uint32_t n_tiles, int stack, int grid_blocks,
-                       hipStream_t st) {
+                       uint32_t* cursor, int refill, hipStream_t st) {
     if (S.n_sweep > 0 && S.lean)
         hipLaunchKernelGGL((k_extend<T, 1, WALK_SWEEP_LEAN>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (S.n_sweep > 0 && stack <= 16)
@@ -1593,10 +1824,25 @@ void Launch<T>::extend(const DScene<T>& S, const DSmallScene& small, const DBatc
         else if (stack <= 32) RT_EXTEND(32, MODE); \
         else RT_EXTEND(64, MODE);              \
     } while (0)
+#define RT_REFILL(STACK, MODE)                                                                                                \
+    hipLaunchKernelGGL((k_extend_refill<T, STACK, MODE>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, B, q, h, tmin, tmax, depth, \
+                       tile_offsets, n_tiles, cursor, (uint32_t)refill)
+#define RT_REFILL4(MODE)                       \
+    do {                                       \
+        if (stack <= 16) RT_REFILL(16, MODE);  \
+        else if (stack <= 32) RT_REFILL(32, MODE); \
+        else RT_REFILL(64, MODE);              \
+    } while (0)
+    else if (S.nodes4 && refill > 0 && S.has_meshes && S.has_media) RT_REFILL4(WALK_NODE2_MESH4);
+    else if (S.nodes4 && refill > 0 && S.has_meshes) RT_REFILL4(WALK_NODE4_MESH);
+    else if (S.nodes4 && refill > 0 && S.has_media) RT_REFILL4(WALK_NODE4_MEDIA);
+    else if (S.nodes4 && refill > 0) RT_REFILL4(WALK_NODE4_PLAIN);
     else if (S.nodes4 && S.has_meshes && S.has_media) RT_EXTEND4(WALK_NODE2_MESH4);
     else if (S.nodes4 && S.has_meshes) RT_EXTEND4(WALK_NODE4_MESH);
     else if (S.nodes4 && S.has_media) RT_EXTEND4(WALK_NODE4_MEDIA);
     else if (S.nodes4) RT_EXTEND4(WALK_NODE4_PLAIN);
+#undef RT_REFILL4
+#undef RT_REFILL
 #undef RT_EXTEND4
 #undef RT_EXTEND
     else if (stack <= 16)

@@ -198,7 +198,7 @@ struct Launch {
                        hipStream_t st);
     static void extend(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
                        uint32_t depth, const uint32_t* tile_offsets, uint32_t n_tiles, int stack, int grid_blocks,
-                       hipStream_t st);
+                       uint32_t* cursor /* zeroed */, int refill /* 0: one ray per lane and grid stride */, hipStream_t st);
     // extend + shade of one bounce in one launch (render path).
     static void bounce(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> qin, DQueue<T> qout,
                        T* sample_rgb, uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets,
