@@ -334,6 +334,7 @@ private:
     // ---- BVHNode::from_vec (src/hitting.rs:148-197) over boxed items [lo, hi).
     // Axis: the reference draws it at random (:158); here it is the longest axis of the
     // union of the items' boxes, ties to the lower axis (the oracle uses the same rule).
+    int32_t leaf_base_ = -1;
     int32_t build_bvh(std::vector<BuildItem>& items, size_t lo, size_t hi, int leaf_kind, int* depth, Box* box_out) {
         int32_t idx = (int32_t)out_.nodes.size();
         out_.nodes.emplace_back();
@@ -342,7 +343,9 @@ private:
             std::memset(&n, 0, sizeof(n));
             store(n.lo, items[lo].node_box.lo);  // the leaf's own bounds (never tested by the reference)
             store(n.hi, items[lo].node_box.hi);
-            n.left = -1 - items[lo].payload;
+            // (leaf_base_ >= 0: the payload is the item's final position - items are in depth-first leaf order
+            // by the time a leaf is made, see the Mesh case)
+            n.left = -1 - (leaf_base_ >= 0 ? leaf_base_ + (int32_t)lo : items[lo].payload);
             n.right = leaf_kind;
             out_.nodes[(size_t)idx] = n;
             if (box_out) *box_out = items[lo].node_box;
@@ -501,20 +504,27 @@ private:
             case ObjectDef::Mesh:  // load_mesh: BVHNode::from_vec(triangles, TIME_MIN, TIME_MAX), :719-762
                 if (blas_root_[(size_t)oi] < 0) {
                     const MeshData& md = sc_.meshes[(size_t)o.mesh];
+                    // The triangle records are laid out in the depth-first leaf order of the tree (neighbours in
+                    // space are neighbours in memory: the walks fetch them through 128-byte cache lines); `sub`
+                    // keeps the triangle's index in the mesh.
                     std::vector<BuildItem> items;
                     items.reserve(md.triangles.size());
                     for (size_t k = 0; k < md.triangles.size(); k++) {
                         const MeshTriangle& t = md.triangles[k];
-                        V3 n = v3(t.normal);
-                        int32_t ti = (int32_t)out_.triangles.size();
-                        out_.triangles.push_back(make_triangle(v3(t.p[0]), v3(t.p[1]), v3(t.p[2]),
-                                                               t.has_normal ? &n : nullptr, o.material, oi, (int)k));
                         Box b = tri_box(v3(t.p[0]), v3(t.p[1]), v3(t.p[2]));
-                        items.push_back(BuildItem{ti, b, b});
+                        items.push_back(BuildItem{(int32_t)k, b, b});
                     }
                     int d = 0;
+                    leaf_base_ = (int32_t)out_.triangles.size();
                     blas_root_[(size_t)oi] = build_bvh(items, 0, items.size(), RT_LEAF_TRIANGLE, &d, nullptr);
+                    leaf_base_ = -1;
                     blas_depth_[(size_t)oi] = d;
+                    for (const BuildItem& it : items) {
+                        const MeshTriangle& t = md.triangles[(size_t)it.payload];
+                        V3 n = v3(t.normal);
+                        out_.triangles.push_back(make_triangle(v3(t.p[0]), v3(t.p[1]), v3(t.p[2]),
+                                                               t.has_normal ? &n : nullptr, o.material, oi, it.payload));
+                    }
                 }
                 r.kind = RT_OBJ_BLAS;
                 r.first = blas_root_[(size_t)oi];
