@@ -204,7 +204,10 @@ def main() -> None:
     # (origin, direction, time, path id) and its hit record written once; the scene is read once.
     # The records a traversal touches again and again (SURVEY.md 8d's per-ray sum) are served by
     # LDS / L2 / Infinity Cache and are reported separately as `touched`.
-    rays_per_launch = rays / max(n_extend, 1.0)
+    # (the tail launch of a two-kernel render is another kernel: its rays and time are reported apart)
+    rays_tail = float(sum(s.rays_tail for s in stats))
+    ms_tail = float(sum(s.ms_tail for s in stats))
+    rays_per_launch = (rays - rays_tail) / max(n_extend, 1.0)
     ms_per_launch = ms_extend / max(n_extend, 1.0)
     # Small worlds of rects and spheres run extend + shade as ONE kernel per bounce (k_bounce; the
     # library reports its time as ms_extend and no shade launches): it reads a path's queue entry
@@ -222,8 +225,8 @@ def main() -> None:
         bytes_per_ray = r["ray"] + r["hit"]
     achieved_gbs = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
     touched_bpr = extend_bytes_per_ray(args.scene, args.precision)
-    touched_gbs = touched_bpr * rays / (ms_extend * 1e-3) / 1e9 if ms_extend > 0 else 0.0
-    flops = extend_flops_per_ray(args.scene) * rays / (ms_extend * 1e-3) / 1e12 if ms_extend > 0 else 0.0
+    touched_gbs = touched_bpr * (rays - rays_tail) / (ms_extend * 1e-3) / 1e9 if ms_extend > 0 else 0.0
+    flops = extend_flops_per_ray(args.scene) * (rays - rays_tail) / (ms_extend * 1e-3) / 1e12 if ms_extend > 0 else 0.0
     valu_peak = FP64_VALU_PEAK_TFLOPS if args.precision == "f64" else FP32_VALU_PEAK_TFLOPS
     out = {
         "metric": "Mrays/sec (whole node)",
@@ -255,7 +258,8 @@ def main() -> None:
                     "(see roofline_valu, profiles/ and DESIGN.md)",
         },
         "roofline_valu": {"kernel": kernel, "achieved": flops, "peak": valu_peak, "unit": "TFLOP/s", "frac": flops / valu_peak},
-        "stage_ms_per_step": {"extend": ms_extend / args.steps, "shade": float(t[4]) / args.steps, "gpu_total": float(t[5]) / args.steps},
+        "stage_ms_per_step": {"extend": ms_extend / args.steps, "shade": float(t[4]) / args.steps, "tail": ms_tail / args.steps,
+                              "gpu_total": float(t[5]) / args.steps},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene_path, W, args.bounces, args.seed)

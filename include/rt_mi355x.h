@@ -219,6 +219,12 @@ typedef struct rt_stats {
     double ms_shade;      /* time inside the shade (+compaction) kernel */
     uint32_t extend_launches, shade_launches;
     uint32_t batches, max_depth_reached;
+    /* Two-kernel bounces only (shade_launches > 0): the launch that carries the last few paths through
+     * all their remaining bounces is another kernel (k_bounce) and is kept apart; where one fused kernel
+     * runs every bounce it is counted with ms_extend / extend_launches and these stay 0. */
+    double ms_tail;       /* time inside tail launches */
+    uint64_t rays_tail;   /* closest-hit queries issued inside tail launches (part of `rays`) */
+    uint32_t tail_launches, reserved;
 } rt_stats;
 
 /* Replaces the row closure of src/main.rs:124-137 (+ cast_ray, src/hitting.rs:11-31) for

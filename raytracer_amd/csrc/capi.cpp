@@ -248,7 +248,7 @@ struct Engine : EngineBase {
         std::memset(&S, 0, sizeof(S));
         HIP_CHECK(hipHostMalloc((void**)&host_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
         counts.ensure(4);  // [0] live paths after the last scan, [1] spare, [2] deepest bounce reached inside a tail launch
-        ray_total.ensure(1);
+        ray_total.ensure(2);  // [0] closest-hit queries, [1] those issued inside a tail launch beyond its first bounce
     }
     ~Engine() override {
         if (host_counts) (void)hipHostFree(host_counts);
@@ -996,17 +996,21 @@ struct Engine : EngineBase {
     // and object tests in separate phases, rays handed out from a launch-wide cursor (counts[1], zeroed
     // here).  RT_REFILL=n: 0 = k_extend for every scene; n < 64 = lanes also take new rays while others of
     // their wave still walk, as soon as n lanes wait (measured: slower).
-    void launch_extend(const rtd::DBatch& B, rtd::DQueue<T> q, rtd::DHits<T> h, const T* tmin, const T* tmax, uint32_t depth,
-                       uint32_t n_tiles, int grid) {
+    int refill_lanes() const {
         int refill = 0;
         if (S.nodes4 && S.n_sweep == 0 && !small.blob) {
             refill = S.has_meshes ? 0 : 64;
             if (const char* e = std::getenv("RT_REFILL")) refill = (int)std::strtol(e, nullptr, 10);
         }
-        if (refill > 0) {
-            HIP_CHECK(hipMemsetAsync(counts.p + 1, 0, sizeof(uint32_t), stream));
-            grid = std::min(grid, num_cus * 4);
-        }
+        return refill;
+    }
+    void prepare_extend() {  // (before the launch's timing event)
+        if (refill_lanes() > 0) HIP_CHECK(hipMemsetAsync(counts.p + 1, 0, sizeof(uint32_t), stream));
+    }
+    void launch_extend(const rtd::DBatch& B, rtd::DQueue<T> q, rtd::DHits<T> h, const T* tmin, const T* tmax, uint32_t depth,
+                       uint32_t n_tiles, int grid) {
+        const int refill = refill_lanes();
+        if (refill > 0) grid = std::min(grid, num_cus * 4);
         rtd::Launch<T>::extend(S, small, B, q, h, tmin, tmax, depth, tile_offsets.p, n_tiles, stack_depth, grid, counts.p + 1, refill, stream);
     }
     static uint32_t tiles_for(size_t n) { return (uint32_t)((n + RT_TILE - 1) / RT_TILE); }
@@ -1036,6 +1040,7 @@ struct Engine : EngineBase {
             T* tmax = tminmax.p + capacity;
             rtd::Launch<T>::load_rays(io_f64.p, (uint32_t)m, q, tmin, tmax, tile_counts[0].p, stream);
             rtd::launch_scan_tiles(tile_counts[0].p, tiles_for(m), tile_offsets.p, nullptr, counts.p, nullptr, stream);
+            prepare_extend();
             launch_extend(B, q, h, tmin, tmax, 0, tiles_for(m), grid_for(m));
             rtd::Launch<T>::store_hits(q, h, (uint32_t)m, io_hits.p, stream);
             HIP_CHECK(hipGetLastError());
@@ -1082,7 +1087,7 @@ struct Engine : EngineBase {
         uint32_t spb = (ns + n_batches - 1) / n_batches;
         ensure_capacity((size_t)(npix * spb), false);
         sample_rgb.ensure((size_t)(npix * spb) * 3);
-        HIP_CHECK(hipMemsetAsync(ray_total.p, 0, sizeof(unsigned long long), stream));
+        HIP_CHECK(hipMemsetAsync(ray_total.p, 0, 2 * sizeof(unsigned long long), stream));
         HIP_CHECK(hipMemsetAsync(counts.p + 2, 0, sizeof(uint32_t), stream));
         size_t ev = 0;
         const bool timing = stats != nullptr;
@@ -1096,7 +1101,8 @@ struct Engine : EngineBase {
         // measured: knight 78.8 / 69.0 / 67.0 / 68.5 ms at 0 / 64 k / 128 k / 600 k, cornell 24.85 / 24.7 / 24.4 / 24.2
         uint32_t tail_threshold = fused ? 524288u : 131072u;
         if (const char* e = std::getenv("RT_TAIL")) tail_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
-        std::vector<std::pair<size_t, int>> spans;  // (first event index, 0 = extend / 1 = shade)
+        std::vector<std::pair<size_t, int>> spans;  // (first event index, 0 = extend / 1 = shade / 2 = tail launch next to k_extend)
+        uint64_t tail_first_bounce = 0;
         hipEvent_t ev_begin = event(ev++), ev_end = event(ev++);
         if (timing) HIP_CHECK(hipEventRecord(ev_begin, stream));
         uint32_t deepest = 0;
@@ -1114,6 +1120,7 @@ struct Engine : EngineBase {
                                    max_bounces ? ray_total.p : nullptr, stream);
             for (uint32_t depth = 0; depth < max_bounces; depth++) {
                 int in = depth & 1, out = in ^ 1;
+                if (!fused) prepare_extend();
                 if (timing) {
                     spans.push_back({ev, 0});
                     HIP_CHECK(hipEventRecord(event(ev), stream));
@@ -1147,9 +1154,10 @@ struct Engine : EngineBase {
                         // The few paths left go through all their remaining bounces in ONE launch, each at its
                         // own pace, instead of one launch per bounce that waits for the slowest ray (k_bounce,
                         // DTail).  Its time is reported with the extend kernel's.
-                        const rtd::DTail tail{ray_total.p, counts.p + 2};
+                        const rtd::DTail tail{ray_total.p + 1, counts.p + 2};
+                        tail_first_bounce += host_counts[0];
                         if (timing) {
-                            spans.push_back({ev, 0});
+                            spans.push_back({ev, fused ? 0 : 2});
                             HIP_CHECK(hipEventRecord(event(ev), stream));
                         }
                         rtd::Launch<T>::bounce(S, small, B, queue(out), queue(in), sample_rgb.p, depth + 1, max_bounces,
@@ -1165,13 +1173,14 @@ struct Engine : EngineBase {
             HIP_CHECK(hipGetLastError());
         }
         if (timing) HIP_CHECK(hipEventRecord(ev_end, stream));
-        unsigned long long total = 0;
-        HIP_CHECK(hipMemcpyAsync(&total, ray_total.p, sizeof(total), hipMemcpyDeviceToHost, stream));
+        unsigned long long totals[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(totals, ray_total.p, sizeof(totals), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipMemcpyAsync(host_counts + 2, counts.p + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         deepest = std::max(deepest, std::min(host_counts[2], max_bounces));
         if (stats) {
-            stats->rays = total;
+            stats->rays = totals[0] + totals[1];
+            if (!fused) stats->rays_tail = tail_first_bounce + totals[1];
             stats->paths = npix * ns;
             stats->batches = n_batches;
             stats->max_depth_reached = deepest;
@@ -1183,6 +1192,9 @@ struct Engine : EngineBase {
                 if (sp.second == 0) {
                     stats->ms_extend += ms;
                     stats->extend_launches++;
+                } else if (sp.second == 2) {
+                    stats->ms_tail += ms;
+                    stats->tail_launches++;
                 } else {
                     stats->ms_shade += ms;
                     stats->shade_launches++;
@@ -1399,6 +1411,7 @@ int rt_render_rows(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0
                 stats->rays += part.rays; stats->paths += part.paths;
                 stats->ms_total += part.ms_total; stats->ms_extend += part.ms_extend; stats->ms_shade += part.ms_shade;
                 stats->extend_launches += part.extend_launches; stats->shade_launches += part.shade_launches;
+                stats->ms_tail += part.ms_tail; stats->rays_tail += part.rays_tail; stats->tail_launches += part.tail_launches;
                 stats->batches += part.batches;
                 stats->max_depth_reached = std::max(stats->max_depth_reached, part.max_depth_reached);
             }

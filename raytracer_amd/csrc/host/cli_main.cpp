@@ -334,6 +334,7 @@ int run(const Opt& opt) {
         total.ms_total += st.ms_total;
         total.ms_extend += st.ms_extend;
         total.ms_shade += st.ms_shade;
+        total.ms_tail += st.ms_tail;
         total.batches += st.batches;
         for (uint32_t j = hi; j-- > lo;) {
             const uint8_t* row = &band_rgb[(size_t)(j - lo) * row_bytes];
@@ -349,9 +350,9 @@ int run(const Opt& opt) {
     rt::save_image(opt.output_file, width, height, pixels.data());
 
     if (opt.stats)
-        std::fprintf(stderr, "seed %llu: %llu paths, %llu rays, %.2f ms on the GPU (extend %.2f, shade %.2f), %.1f Mrays/s\n",
+        std::fprintf(stderr, "seed %llu: %llu paths, %llu rays, %.2f ms on the GPU (extend %.2f, shade %.2f, tail %.2f), %.1f Mrays/s\n",
                      (unsigned long long)seed, (unsigned long long)total.paths, (unsigned long long)total.rays, total.ms_total,
-                     total.ms_extend, total.ms_shade, total.ms_total > 0 ? (double)total.rays / total.ms_total * 1e-3 : 0.0);
+                     total.ms_extend, total.ms_shade, total.ms_tail, total.ms_total > 0 ? (double)total.rays / total.ms_total * 1e-3 : 0.0);
     if (!opt.quiet) {
         auto elapsed = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - render_start).count();
         std::fprintf(stderr, "Completed in %lld:%02lld\n", (long long)(elapsed / 60), (long long)(elapsed % 60));
