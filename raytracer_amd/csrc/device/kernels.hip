@@ -1476,7 +1476,7 @@ __device__ __noinline__ int resolve_checkered(const DScene<T>& S, int mi, T u, T
 // One bounce of cast_ray for one path (src/hitting.rs:11-31) after its closest-hit query: adds what
 // the path sees (light / sky) to its sample, and scatters.  mf = material | front_face << 31, or
 // RT_MISS.  Returns true if the path goes on: nr is the scattered ray, thr the new throughput.
-template <typename T>
+template <typename T, bool SHARED_DRAW = true>
 __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, const Ray<T>& ray, V3<T>& thr, uint32_t pid,
                                            uint32_t mf, T t, V3<T> n, T u, T v, T* sample_rgb, uint32_t depth,
                                            uint32_t max_bounces, Ray<T>& nr) {
@@ -1526,12 +1526,24 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
         V3<T> attenuation = mk((T)1.0, (T)1.0, (T)1.0);
         V3<T> dir = n;
         bool scattered = false, metal = false;
+        // Lambertian, Metal and Isotropic each begin with one random_in_unit_sphere (src/materials.rs:33, 58,
+        // 148): drawn here, once, so that the lanes of a wave with mixed materials run the rejection loop
+        // (the dearest part of the shading) together instead of once per material.  (SHARED_DRAW = false:
+        // drawn inside each case - 1 % faster where nearly every hit is Lambertian, the lean sweep's k_bounce.)
+        V3<T> in_sphere = mk((T)0.0, (T)0.0, (T)0.0);
+#if defined(RT_EXP) && (RT_EXP & 2)  // timing experiment only: no random numbers for Lambertian
+        if (SHARED_DRAW && (m.type == RT_MAT_METAL || m.type == RT_MAT_ISOTROPIC)) in_sphere = random_in_unit_sphere(rng);
+#else
+        if (SHARED_DRAW && (m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_METAL || m.type == RT_MAT_ISOTROPIC))
+            in_sphere = random_in_unit_sphere(rng);
+#endif
         switch (m.type) {
             case RT_MAT_LAMBERTIAN: {  // src/materials.rs:27-42
-#if defined(RT_EXP) && (RT_EXP & 2)  // timing experiment only: no random numbers
+#if defined(RT_EXP) && (RT_EXP & 2)
                 dir = n + mk((T)0.1, (T)0.2, (T)0.3) * ray.d.x;
 #else
-                dir = n + unit_vector(random_in_unit_sphere(rng));
+                if (!SHARED_DRAW) in_sphere = random_in_unit_sphere(rng);
+                dir = n + unit_vector(in_sphere);
 #endif
                 if (near_zero(dir)) dir = n;
                 attenuation = texture_value(S, m, u, v);
@@ -1540,7 +1552,8 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
             }
             case RT_MAT_METAL: {  // :53-66
                 V3<T> reflected = reflect(unit_vector(ray.d), n);
-                dir = reflected + m.param * random_in_unit_sphere(rng);
+                if (!SHARED_DRAW) in_sphere = random_in_unit_sphere(rng);
+                dir = reflected + m.param * in_sphere;
                 attenuation = ld3(m.colour);
                 metal = true;
                 scattered = true;
@@ -1559,7 +1572,8 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
                 break;
             }
             case RT_MAT_ISOTROPIC: {  // :146-153
-                dir = random_in_unit_sphere(rng);
+                if (!SHARED_DRAW) in_sphere = random_in_unit_sphere(rng);
+                dir = in_sphere;
                 attenuation = texture_value(S, m, u, v);
                 scattered = true;
                 break;
@@ -1697,7 +1711,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_bounce(DScene<T> S, 
                     mf = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
 #endif
                 }
-                alive = shade_path(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
+                alive = shade_path<T, MODE != WALK_SWEEP_LEAN>(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
                 if (!run_tail || !alive) break;
                 ray = nr;  // the scattered ray is the next bounce's query
                 extra_queries++;
