@@ -272,7 +272,7 @@ int rt_part_file_read(const char* name, uint32_t image_height, uint32_t image_wi
                       uint8_t* rows, uint8_t* present);
 
 /* img.save(output_file) (src/main.rs:161-162): rgb8 is width*height*3 bytes, top row first; the
- * encoder follows the extension (.png, .ppm/.pnm, .bmp; anything else is RT_ERR_IO). */
+ * encoder follows the extension (.png, .jpg/.jpeg - baseline JFIF, quality 75 -, .ppm/.pnm, .bmp; anything else is RT_ERR_IO). */
 int rt_save_image(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb8);
 
 /* TimedProgressBar (src/progress.rs:12-115) drawing on a duplicate of file descriptor fd. */

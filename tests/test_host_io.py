@@ -2,6 +2,7 @@
 (reference src/part_file.rs), output images (src/main.rs:161-162), the progress bar
 (src/progress.rs) and the argument handling of bin/raytracer (struct Opt, src/main.rs:32-71).
 The reference has no tests for these; the expectations below restate its format strings."""
+import ctypes as C
 import os
 import struct
 import subprocess
@@ -144,6 +145,54 @@ def test_save_png_ppm_bmp(in_tmp):
     stride = 16
     body = np.frombuffer(raw[54:], dtype=np.uint8).reshape(7, stride)[:, :15].reshape(7, 5, 3)
     assert np.array_equal(body[::-1, :, ::-1], img)
+
+
+def _test_picture(h, w):
+    y, x = np.mgrid[0:h, 0:w]
+    rng = np.random.default_rng(3)
+    img = np.stack([128 + 100 * np.sin(x / 9.0), 128 + 100 * np.cos(y / 7.0), 40 + 2.0 * x + 1.0 * y], axis=2)
+    img += rng.normal(0, 4, img.shape)
+    img[h // 3: h // 3 + 5, :, :] = 255          # a hard edge and saturated values
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (45, 61), (8, 8), (1, 1), (3, 130)])
+def test_save_jpeg_decodes_to_the_input(in_tmp, shape):
+    # lossy, so parity with the image crate's encoder is unpinned; any baseline decoder must read the file
+    # and give the picture back within the error of quality 75
+    from PIL import Image
+
+    img = _test_picture(*shape)
+    rt.save_image("a.jpg", img)
+    raw = open("a.jpg", "rb").read()
+    assert raw[:4] == b"\xff\xd8\xff\xe0" and raw[6:10] == b"JFIF" and raw[-2:] == b"\xff\xd9"
+    back = np.asarray(Image.open("a.jpg").convert("RGB"), dtype=np.float64)
+    assert back.shape == img.shape
+    mse = ((back - img) ** 2).mean()
+    assert 10 * np.log10(255.0 ** 2 / max(mse, 1e-9)) > (30.0 if min(shape) >= 8 else 20.0)
+    rt.save_image("b.JPEG", img)
+    assert open("b.JPEG", "rb").read() == raw
+
+
+def test_saved_jpeg_is_read_by_the_scene_loader(in_tmp):
+    # the library's own JPEG decoder (image textures, src/textures.rs:32-36) reads what the encoder writes
+    img = _test_picture(40, 56)
+    rt.save_image("tex.jpg", img)
+    text = """{
+      camera: {lookFrom: [0,0,-5], lookAt: [0,0,0], directionUp: [0,1,0], fieldOfView: 40, aspectRatio: [1,1],
+               aperture: 0, distanceToFocus: 5, startTime: 0, endTime: 1},
+      background: {type: "plainColour", colour: [0,0,0]},
+      textures: {t: {type: "imageTexture", filename: "tex.jpg"}},
+      materials: {m: {type: "lambertian", texture: "t"}},
+      objects: {s: {type: "sphere", centre: [0,0,0], radius: 1, material: "m"}},
+      world: ["s"],
+    }"""
+    sc = rt.Scene.from_text(text, ".")
+    assert sc.counts()["texels"] == img.size
+    raw = (C.c_uint64 * 24).from_address(sc.desc_ptr)
+    got = np.ctypeslib.as_array((C.c_uint8 * img.size).from_address(raw[22])).reshape(img.shape).astype(np.float64)
+    mse = ((got - img) ** 2).mean()
+    assert 10 * np.log10(255.0 ** 2 / mse) > 30.0
 
 
 def test_save_unknown_extension(in_tmp):
