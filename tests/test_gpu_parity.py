@@ -348,3 +348,90 @@ def test_checkers_that_emit_and_checkers_that_do_not(rt, orc):
     assert close.mean() >= 0.99
     assert abs(int(st.rays) - orays) <= 0.002 * orays
     assert sums.max() > 1.0  # the lamps are seen
+
+
+def _corners_scene(tmp, with_mesh, extra_spheres):
+    """Every object kind and wrapper of the schema in one world: moving sphere, lone
+    triangle, plane, rotateX / rotateY / rotateZ around translate, spotlight, media bounded by a sphere, a block
+    and (with_mesh) a mesh, nested checker, image-free materials of every type."""
+    objs = """
+        ball: {type: "sphere", centre: [0,1,0], radius: 1, material: "glass"},
+        mover: {type: "movingSphere", centre0: [-2.5,0.6,0.5], centre1: [-2.5,1.4,0.5], time0: 0, time1: 1, radius: 0.6, material: "red"},
+        tri: {type: "triangle", point0: [1.5,0,1.5], point1: [3.5,0,1.0], point2: [2.5,2.2,1.8], material: "mirror"},
+        crate: {type: "block", corner0: [-0.5,-0.5,-0.5], corner1: [0.5,0.5,0.5], material: "check"},
+        crateX: {type: "rotateX", prototype: "crate", degrees: 25},
+        crateXY: {type: "rotateY", prototype: "crateX", degrees: 40},
+        crateXYZ: {type: "rotateZ", prototype: "crateXY", degrees: -15},
+        crateAt: {type: "translate", prototype: "crateXYZ", offset: [2.2,0.8,-1.2]},
+        fogBall: {type: "sphere", centre: [-1.5,1.2,-1.5], radius: 0.9, material: "glass"},
+        fog: {type: "constantMedium", boundary: "fogBall", phaseFunction: "mist", density: 1.5},
+        hazeBox: {type: "block", corner0: [-6,-1,-6], corner1: [6,6,6], material: "glass"},
+        haze: {type: "constantMedium", boundary: "hazeBox", phaseFunction: "mist", density: 0.02},
+        lamp: {type: "spotlight", lookFrom: [0,5,-1], lookAt: [0,0,0], length: 1.0, width: 1.5, light: [9,8,7]},
+        ground: {type: "plane", point0: [0,0,0], point1: [1,0,0], point2: [0,0,1], uvRepeat: 2.0, material: "check"},
+    """
+    world = ["ball", "mover", "tri", "crateAt", "fog", "haze", "lamp", "ground"]
+    if with_mesh:
+        obj = os.path.join(tmp, "tetra.obj")
+        with open(obj, "w") as f:
+            f.write("v 0 0 0\nv 1.6 0 0\nv 0.8 0 1.4\nv 0.8 1.5 0.5\nf 1 3 2\nf 1 2 4\nf 2 3 4\nf 3 1 4\n")
+        objs += """
+        tetra: {type: "mesh", filename: "%s", material: "red"},
+        tetraAt: {type: "translate", prototype: "tetra", offset: [-0.5,0,-3.2]},
+        cloudShape: {type: "translate", prototype: "tetra", offset: [0.8,0,2.2]},
+        cloud: {type: "constantMedium", boundary: "cloudShape", phaseFunction: "mist", density: 2.5},
+        """ % obj
+        world += ["tetraAt", "cloud"]
+    for k in range(extra_spheres):
+        objs += 'p%d: {type: "sphere", centre: [%g,0.25,%g], radius: 0.25, material: "%s"},\n' % (
+            k, -4.0 + 0.6 * (k % 15), 2.6 + 0.6 * (k // 15), ["red", "mirror", "glass"][k % 3])
+        world.append("p%d" % k)
+    return """{
+      camera: {lookFrom: [0.5,2.5,-8], lookAt: [0,1,0], directionUp: [0,1,0], fieldOfView: 45, aspectRatio: [4,3],
+               aperture: 0.05, distanceToFocus: 8, startTime: 0, endTime: 1},
+      background: {type: "gradient", direction: [0,1,0], colour0: [0.9,0.9,1.0], colour1: [0.3,0.5,0.9]},
+      textures: {r: {type: "solidColour", colour: [0.8,0.2,0.2]}, w: {type: "solidColour", colour: [0.9,0.9,0.9]},
+                 k: {type: "solidColour", colour: [0.1,0.1,0.1]}, m: {type: "solidColour", colour: [0.7,0.7,0.8]}},
+      materials: {red: {type: "lambertian", texture: "r"}, white: {type: "lambertian", texture: "w"},
+                  black: {type: "lambertian", texture: "k"}, mirror: {type: "metal", albedo: [0.9,0.8,0.7], fuzz: 0.1},
+                  glass: {type: "dielectric", indexOfRefraction: 1.5}, mist: {type: "isotropic", albedo: "m"},
+                  tiles: {type: "checkered", odd: "white", even: "black", tileDensity: 4},
+                  check: {type: "checkered", odd: "tiles", even: "red", tileDensity: 2}},
+      objects: {%s},
+      world: [%s],
+    }""" % (objs, ", ".join('"%s"' % w for w in world))
+
+
+@pytest.mark.parametrize("with_mesh,extra_spheres", [(False, 0), (False, 14), (False, 150), (True, 0), (True, 150)])
+def test_every_object_kind_against_the_oracle(rt, orc, tmp_path, with_mesh, extra_spheres):
+    # (False, 0): a world of 7 leaves is swept; (False, 14): own-box tree staged in LDS; (False, 150): too large
+    # for LDS - four-wide world tree, k_extend_refill with media; (True, ..): meshes and media together - the
+    # general four-wide kernel, a medium bounded by a mesh
+    text = _corners_scene(str(tmp_path), with_mesh, extra_spheres)
+    scene = rt.Scene.from_text(text)
+    o = orc.OracleScene.from_text(text)
+    r = rt.Renderer(0)
+    r.upload(scene)
+    W = 96
+    H = scene.image_height(W)
+    assert H == o.image_height(W)
+    prim = o.primary_rays(W, H, 0, H, 0, 11)
+    ph = o.trace(prim, 11)
+    check_hits(r.trace(prim, 11), ph, ph["second_t"])
+    rng = np.random.default_rng(5)
+    ok = ph["hit"] == 1
+    n = int(ok.sum())
+    rays = np.zeros(2 * n, dtype=prim.dtype)
+    rays["o"] = np.tile(ph["p"][ok], (2, 1))
+    d = rng.normal(size=(2 * n, 3))
+    rays["d"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["time"] = rng.uniform(0, 1, 2 * n)
+    rays["tmin"] = 0.001
+    rays["tmax"] = np.inf
+    want = o.trace(rays, 12)
+    check_hits(r.trace(rays, 12), want, want["second_t"])
+    rgb8, sums, st = r.render_rows(W, H, 0, H, 8, 20, seed=4)
+    o8, osums, orays = o.render(W, H, 0, H, 8, 20, seed=4, threads=8)
+    close = np.isclose(sums, osums, rtol=1e-6, atol=1e-9).all(axis=2)
+    assert close.mean() >= 0.99, close.mean()
+    assert abs(int(st.rays) - orays) <= 0.002 * orays
