@@ -55,7 +55,10 @@ def test_cli_bands_quiet_and_formats(tmp_path):
     assert (np.abs(f32.astype(int) - whole.astype(int)) <= 2).mean() >= 0.97
     r = _cli(SCENE, "out.png", "-w", str(W), "-s", "2", "-m", "4", "-q", cwd=tmp_path)
     assert r.returncode == 0 and open(os.path.join(tmp_path, "out.png"), "rb").read(8) == b"\x89PNG\r\n\x1a\n"
-    r = _cli(SCENE, "out.jpg", "-w", str(W), "-s", "1", "-m", "2", cwd=tmp_path)
+    r = _cli(SCENE, "out.jpg", "-w", str(W), "-s", "2", "-m", "4", "-q", cwd=tmp_path)
+    raw = open(os.path.join(tmp_path, "out.jpg"), "rb").read()
+    assert r.returncode == 0 and raw[:2] == b"\xff\xd8" and raw[6:10] == b"JFIF" and raw[-2:] == b"\xff\xd9"
+    r = _cli(SCENE, "out.gif", "-w", str(W), "-s", "1", "-m", "2", cwd=tmp_path)
     assert r.returncode == 1 and b"image format" in r.stderr
 
 
