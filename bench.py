@@ -107,6 +107,8 @@ def main() -> None:
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --spp is the whole image's sample count, split over the GPUs (default: weak, --spp per GPU)")
     args = ap.parse_args()
 
     import torch
@@ -146,7 +148,7 @@ def main() -> None:
     dev = torch.device("cuda", local_rank)
     accum = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
     rgb8 = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
-    total_spp = args.spp * world
+    total_spp = args.spp if args.strong else args.spp * world
     s0, ns = parallel.split_samples(total_spp, world, rank)
 
     def barrier():
@@ -237,12 +239,12 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": args.precision,
         "data": "synthetic" if args.scene == "knight" else "reference example scene",
         "config": {
-            "workload": f"examples/{args.scene}.json5 {W}x{H}, {args.spp} spp per GPU ({total_spp} spp image), "
+            "workload": f"examples/{args.scene}.json5 {W}x{H}, {total_spp // world if args.strong else args.spp} spp per GPU ({total_spp} spp image), "
                         f"{args.bounces} bounces, sample-split across {world} GPU(s), reduce to rank 0, quantise",
             "paths_per_step": npix * total_spp, "rays_per_step": rays_all / args.steps,
             "wall_clock_per_image_s": dt / args.steps, "seed": args.seed,
