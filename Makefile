@@ -27,7 +27,7 @@ $(OBJDIR)/kernels.o: raytracer_amd/csrc/device/kernels.hip raytracer_amd/csrc/de
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(OBJDIR)/capi.o: raytracer_amd/csrc/capi.cpp raytracer_amd/csrc/device/rt_device.h $(HOST_HDRS)
+$(OBJDIR)/capi.o: raytracer_amd/csrc/capi.cpp raytracer_amd/csrc/tree_layout.hpp raytracer_amd/csrc/device/rt_device.h $(HOST_HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
