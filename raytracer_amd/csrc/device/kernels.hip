@@ -362,7 +362,7 @@ __device__ __forceinline__ bool box_hit(const DNode<T>& n, V3<T> o, V3<T> inv_d,
 // Conservative f32 slab test against a padded, outward-rounded child box (DNode2).
 // The reference's AABB::intersects (src/hitting.rs:249-268) works in f64 on the exact box and
 // rejects when max <= min; this test may only err towards "hit": the boxes are padded by far
-// more than the f32 rounding of the test (capi.cpp, build_nodes2), tmin is rounded down and the
+// more than the f32 rounding of the test (tree_layout.hpp, box_pad), tmin is rounded down and the
 // bound up, NaN (0 * inf) is ignored by fminf / fmaxf, and equality counts as a hit.  A node
 // that is visited although the reference would have culled it costs time only: its primitives
 // are tested exactly (f64) against the current bound.  Boxes the reference *always* culls
