@@ -298,7 +298,7 @@ struct Engine : EngineBase {
             stack_need4 = 0;
             for (int use_sah = (sah_env && sah_env[0] == '0') ? 0 : 1; use_sah >= 0; use_sah--) {
                 if ((e && e[0] == '0') || d.tlas_root < 0) break;
-                std::vector<rtd::DNode4> v;
+                std::vector<rtd::WideNode4> v;
                 int need = 0, need_world = 0;
                 auto build = [&](int32_t root, int* need_out) {
                     int32_t r = -1;
@@ -319,14 +319,15 @@ struct Engine : EngineBase {
                         need = std::max(need, need_here);
                     }
                 stack_need4 = need + need_world + 3;
-                if (stack_need4 <= lds_part + RT_STACK_OVERFLOW) {
+                std::vector<rtd::DNode4> packed;
+                if (stack_need4 <= lds_part + RT_STACK_OVERFLOW && quantize_nodes4(v, packed)) {
                     if (std::getenv("RT_DEBUG") && v[(size_t)S.tlas_root4].child[0] >= 0) {
-                        const rtd::DNode4& w = v[(size_t)v[(size_t)S.tlas_root4].child[0]];
+                        const rtd::WideNode4& w = v[(size_t)v[(size_t)S.tlas_root4].child[0]];
                         for (int k = 0; k < 4; k++)
                             std::fprintf(stderr, "  world slot %d: child %d  [%g %g %g] - [%g %g %g]\n", k, w.child[k], w.lo[0][k], w.lo[1][k],
                                          w.lo[2][k], w.hi[0][k], w.hi[1][k], w.hi[2][k]);
                     }
-                    nodes4.upload(v);
+                    nodes4.upload(packed);
                     S.nodes4 = nodes4.p;
                     sah_trees = use_sah != 0;
                     break;

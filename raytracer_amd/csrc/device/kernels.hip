@@ -500,17 +500,19 @@ __device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_di
     return found;
 }
 
-struct alignas(16) Node4Regs {  // a DNode4 fetched as seven 16-byte loads (the padding stays behind)
-    uint4 q[7];
-    __device__ __forceinline__ const float* lo(int axis) const { return (const float*)&q[axis]; }
-    __device__ __forceinline__ const float* hi(int axis) const { return (const float*)&q[3 + axis]; }
-    __device__ __forceinline__ int32_t child(int c) const { return ((const int32_t*)&q[6])[c]; }
+struct alignas(16) Node4Regs {  // a DNode4 fetched as four 16-byte loads
+    uint4 q[4];
+    __device__ __forceinline__ float origin(int axis) const { return __uint_as_float(((const uint32_t*)q)[axis]); }
+    __device__ __forceinline__ float step(int axis) const { return __uint_as_float(((const uint32_t*)q)[3 + axis]); }
+    __device__ __forceinline__ uint32_t qlo(int axis) const { return ((const uint32_t*)q)[6 + axis]; }  // four slots, one byte each
+    __device__ __forceinline__ uint32_t qhi(int axis) const { return ((const uint32_t*)q)[9 + axis]; }
+    __device__ __forceinline__ int32_t child(int c) const { return ((const int32_t*)q)[12 + c]; }
 };
 __device__ __forceinline__ Node4Regs load_node4(const DNode4* nodes, int idx) {
     const uint4* p = (const uint4*)(nodes + idx);
     Node4Regs n;
 #pragma unroll
-    for (int k = 0; k < 7; k++) n.q[k] = p[k];
+    for (int k = 0; k < 4; k++) n.q[k] = p[k];
     return n;
 }
 __device__ __forceinline__ void order2(float& ka, int32_t& ca, float& kb, int32_t& cb) {  // compare-exchange
@@ -539,10 +541,12 @@ extern "C" void rt_exp_prof(unsigned long long* out, int reset) {
 #define RT_PROF_FLUSH
 #endif
 
-// One step of a four-wide walk: the four child boxes of `n` against the ray (the arithmetic of
-// box2_hit, operation for operation, without branches: one plane of all four children per pair of
-// packed operations), the children that are hit ordered nearest first (or left to right), all but
-// the first pushed - farthest first - and the first returned (RT_EMPTY: none was hit).
+// One step of a four-wide walk: the four child boxes of `n` against the ray, without branches - a
+// plane's distance is fma(q, step / d, (origin - o) / d) with q the plane's 8-bit offset, one
+// packed operation per pair of children; NaN (0 * inf on an axis the ray does not move along)
+// leaves that axis out, like fminf / fmaxf in box2_hit - then the children that are hit ordered
+// nearest first (or left to right), all but the first pushed - farthest first - and the first
+// returned (RT_EMPTY: none was hit).
 typedef float float2v __attribute__((ext_vector_type(2)));
 template <typename ST>
 __device__ __forceinline__ int32_t node4_step(const Node4Regs& n, const RayF& f, float tmin32, float bound32, bool ordered,
@@ -553,13 +557,14 @@ __device__ __forceinline__ int32_t node4_step(const Node4Regs& n, const RayF& f,
     const float o[3] = {f.ox, f.oy, f.oz}, inv[3] = {f.ix, f.iy, f.iz};
 #pragma unroll
     for (int axis = 0; axis < 3; axis++) {
-        const float2v o2 = {o[axis], o[axis]}, i2 = {inv[axis], inv[axis]};
-        const float* lo = n.lo(axis);
-        const float* hi = n.hi(axis);
+        const float a = n.step(axis) * inv[axis], b = (n.origin(axis) - o[axis]) * inv[axis];
+        const float2v a2 = {a, a}, b2 = {b, b};
+        const uint32_t ql = n.qlo(axis), qh = n.qhi(axis);
 #pragma unroll
         for (int pair = 0; pair < 2; pair++) {
-            const float2v lo2 = {lo[2 * pair], lo[2 * pair + 1]}, hi2 = {hi[2 * pair], hi[2 * pair + 1]};
-            const float2v ta = (lo2 - o2) * i2, tb = (hi2 - o2) * i2;
+            const float2v l2 = {(float)((ql >> (16 * pair)) & 0xffu), (float)((ql >> (16 * pair + 8)) & 0xffu)};
+            const float2v h2 = {(float)((qh >> (16 * pair)) & 0xffu), (float)((qh >> (16 * pair + 8)) & 0xffu)};
+            const float2v ta = __builtin_elementwise_fma(l2, a2, b2), tb = __builtin_elementwise_fma(h2, a2, b2);
             near[2 * pair] = fmaxf(fminf(ta.x, tb.x), near[2 * pair]);
             far[2 * pair] = fminf(fmaxf(ta.x, tb.x), far[2 * pair]);
             near[2 * pair + 1] = fmaxf(fminf(ta.y, tb.y), near[2 * pair + 1]);

@@ -26,15 +26,12 @@ struct alignas(16) DNode2 {
 };
 static constexpr int32_t RT_EMPTY = (int32_t)0x80000000;
 
-// Four-wide traversal node (128 B): the reference's binary tree with every other level folded away
-// (or regrouped by SAH), so a walk takes about half as many dependent fetches.  Child references as
-// in DNode2.  Bounds are stored per axis across the four slots (lo[axis][slot]): seven aligned
-// 16-byte loads bring in a node, and one plane of all four children is tested with one pair of
-// packed operations.
-struct alignas(16) DNode4 {
+// Four-wide traversal node as the trees are built on the host (tree_layout.hpp): the reference's
+// binary tree with every other level folded away, or regrouped by SAH.  Child references as in
+// DNode2; bounds are the padded, outward-rounded f32 boxes, per axis across the four slots.
+struct WideNode4 {
     float lo[3][4], hi[3][4];
     int32_t child[4];
-    int32_t pad[4];
     void set_box(int slot, const float* blo, const float* bhi) {
         for (int a = 0; a < 3; a++) {
             lo[a][slot] = blo[a];
@@ -42,6 +39,17 @@ struct alignas(16) DNode4 {
         }
     }
 };
+
+// The same node as the kernels fetch it (64 B, four 16-byte loads - the walks are bound by the number
+// of cache-line look-ups their scattered per-lane fetches cost): the child boxes are
+// 8-bit offsets from the node's own corner, plane = origin[axis] + q * step[axis], rounded outwards
+// when the node is made, so a decoded box contains the padded f32 box it stands for.
+struct alignas(16) DNode4 {
+    float origin[3], step[3];
+    uint8_t qlo[3][4], qhi[3][4];  // [axis][slot]
+    int32_t child[4];
+};
+static_assert(sizeof(DNode4) == 64, "DNode4 is four 16-byte loads");
 
 template <typename T>
 struct alignas(16) DXform {  // world -> object: p' = m p + b

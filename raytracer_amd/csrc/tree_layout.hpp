@@ -133,7 +133,7 @@ inline double half_area(const rt_node& nd) {
 }
 // Child reference for reference node `idx` in the four-wide tree; *need = stack entries a walk below it
 // can hold at once (3 pushed siblings per level in the worst visiting order).
-inline int32_t node4_child(const rt_scene_desc& d, int32_t idx, float pad, std::vector<rtd::DNode4>& out, int* need) {
+inline int32_t node4_child(const rt_scene_desc& d, int32_t idx, float pad, std::vector<rtd::WideNode4>& out, int* need) {
     const rt_node& nd = d.nodes[idx];
     *need = 0;
     if (nd.left < 0) return nd.left;
@@ -160,7 +160,7 @@ inline int32_t node4_child(const rt_scene_desc& d, int32_t idx, float pad, std::
     }
     const int32_t me = (int32_t)out.size();
     out.emplace_back();
-    rtd::DNode4 n;
+    rtd::WideNode4 n;
     std::memset(&n, 0, sizeof(n));
     int deepest = 0, live = 0;
     for (int k = 0; k < 4; k++) {
@@ -178,10 +178,10 @@ inline int32_t node4_child(const rt_scene_desc& d, int32_t idx, float pad, std::
     *need = std::max(0, live - 1) + deepest;
     return me;
 }
-inline int32_t build_nodes4(const rt_scene_desc& d, int32_t root, float pad, std::vector<rtd::DNode4>& out, int* need) {
+inline int32_t build_nodes4(const rt_scene_desc& d, int32_t root, float pad, std::vector<rtd::WideNode4>& out, int* need) {
     const int32_t me = (int32_t)out.size();
     out.emplace_back();
-    rtd::DNode4 n;
+    rtd::WideNode4 n;
     std::memset(&n, 0, sizeof(n));
     for (int k = 0; k < 4; k++) n.child[k] = rtd::RT_EMPTY;
     float blo[3], bhi[3];
@@ -330,7 +330,7 @@ inline size_t sah_split(std::vector<SahLeaf>& L, size_t lo, size_t hi) {
     const size_t m = (size_t)(mid - L.begin());
     return (m == lo || m == hi) ? lo + (hi - lo) / 2 : m;
 }
-inline int32_t sah4_node(std::vector<SahLeaf>& L, size_t lo, size_t hi, std::vector<rtd::DNode4>& out, int* need) {
+inline int32_t sah4_node(std::vector<SahLeaf>& L, size_t lo, size_t hi, std::vector<rtd::WideNode4>& out, int* need) {
     std::vector<SahPart> parts{make_part(L, lo, hi)};
     while (parts.size() < 4) {
         int pick = -1;
@@ -347,7 +347,7 @@ inline int32_t sah4_node(std::vector<SahLeaf>& L, size_t lo, size_t hi, std::vec
     std::stable_sort(parts.begin(), parts.end(), [](const SahPart& a, const SahPart& b) { return a.area > b.area; });
     const int32_t me = (int32_t)out.size();
     out.emplace_back();
-    rtd::DNode4 n;
+    rtd::WideNode4 n;
     std::memset(&n, 0, sizeof(n));
     int deepest = 0;
     for (int k = 0; k < 4; k++) {
@@ -364,12 +364,12 @@ inline int32_t sah4_node(std::vector<SahLeaf>& L, size_t lo, size_t hi, std::vec
     return me;
 }
 // Super-root like build_nodes4's.  false: the tree has leaves without finite bounds, nothing was added.
-inline bool build_sah4(const rt_scene_desc& d, int32_t root, float pad, std::vector<rtd::DNode4>& out, int32_t* root_out, int* need) {
+inline bool build_sah4(const rt_scene_desc& d, int32_t root, float pad, std::vector<rtd::WideNode4>& out, int32_t* root_out, int* need) {
     std::vector<SahLeaf> L;
     if (!collect_leaves(d, root, pad, L)) return false;
     const int32_t me = (int32_t)out.size();
     out.emplace_back();
-    rtd::DNode4 n;
+    rtd::WideNode4 n;
     std::memset(&n, 0, sizeof(n));
     for (int k = 0; k < 4; k++) n.child[k] = rtd::RT_EMPTY;
     *need = 0;
@@ -393,6 +393,53 @@ inline int32_t build_nodes2(const rt_scene_desc& d, int32_t root, float pad, std
     n.child[1] = rtd::RT_EMPTY;
     out[(size_t)me] = n;
     return me;
+}
+
+// WideNode4 -> DNode4: every child box as 8-bit steps from the node's corner.  The kernels evaluate
+// plane distances as fma(q, step * 1/d, (origin - o) * 1/d) in f32; its error (a few 2^-24 of
+// |origin - o| / |d|) is covered by the padding the boxes already carry (box_pad), as long as the
+// planes decoded here - with the same fmaf - lie on or outside the padded planes, which is checked
+// plane by plane.  false: a box without finite bounds cannot be stored this way.
+inline bool quantize_nodes4(const std::vector<rtd::WideNode4>& wide, std::vector<rtd::DNode4>& out) {
+    out.resize(wide.size());
+    for (size_t i = 0; i < wide.size(); i++) {
+        const rtd::WideNode4& w = wide[i];
+        rtd::DNode4 n;
+        std::memset(&n, 0, sizeof(n));
+        for (int k = 0; k < 4; k++) n.child[k] = w.child[k];
+        for (int a = 0; a < 3; a++) {
+            float lo_min = INFINITY, hi_max = -INFINITY;
+            for (int k = 0; k < 4; k++) {
+                if (w.child[k] == rtd::RT_EMPTY) continue;
+                if (!std::isfinite(w.lo[a][k]) || !std::isfinite(w.hi[a][k])) return false;
+                lo_min = std::min(lo_min, w.lo[a][k]);
+                hi_max = std::max(hi_max, w.hi[a][k]);
+            }
+            if (!(lo_min <= hi_max)) {  // no live child
+                lo_min = 0.0f;
+                hi_max = 0.0f;
+            }
+            float step = std::max((hi_max - lo_min) / 255.0f, 1e-30f);
+            while (std::fmaf(255.0f, step, lo_min) < hi_max) step = std::nextafterf(step, INFINITY);
+            if (!std::isfinite(step)) return false;
+            n.origin[a] = lo_min;
+            n.step[a] = step;
+            for (int k = 0; k < 4; k++) {
+                if (w.child[k] == rtd::RT_EMPTY) continue;
+                int qlo = (int)std::floor((w.lo[a][k] - lo_min) / step);
+                qlo = std::min(255, std::max(0, qlo));
+                while (qlo > 0 && std::fmaf((float)qlo, step, lo_min) > w.lo[a][k]) qlo--;
+                int qhi = (int)std::ceil((w.hi[a][k] - lo_min) / step);
+                qhi = std::min(255, std::max(0, qhi));
+                while (qhi < 255 && std::fmaf((float)qhi, step, lo_min) < w.hi[a][k]) qhi++;
+                if (std::fmaf((float)qlo, step, lo_min) > w.lo[a][k] || std::fmaf((float)qhi, step, lo_min) < w.hi[a][k]) return false;
+                n.qlo[a][k] = (uint8_t)qlo;
+                n.qhi[a][k] = (uint8_t)qhi;
+            }
+        }
+        out[i] = n;
+    }
+    return true;
 }
 
 }  // namespace rt_layout
