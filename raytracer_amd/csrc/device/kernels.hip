@@ -288,18 +288,29 @@ __device__ __forceinline__ bool rects_hit_uniform(const DScene<T>& S, const Ray<
 // A Block (src/objects.rs:149-168) is always the rect list z, z, y, y, x, x: with the axes known at
 // compile time the six tests are straight-line code (no per-lane component selects, no branches).
 // Same list rule as rects_hit: every side sees the same [min,max], strict < keeps the first.
+template <typename T, int AXIS>
+__device__ __forceinline__ DRect<T> block_face(const DBlock<T>& b, bool far_side) {  // what rect_axis_test reads of a side
+    constexpr int IA = AXIS == 0 ? 1 : 0, IB = AXIS == 2 ? 1 : 2;
+    DRect<T> q;
+    q.a0 = b.lo[IA]; q.a1 = b.hi[IA]; q.b0 = b.lo[IB]; q.b1 = b.hi[IB];
+    q.k = far_side ? b.hi[AXIS] : b.lo[AXIS];
+    return q;
+}
 template <typename T>
-__device__ __forceinline__ bool block6_hit(const DScene<T>& S, const Ray<T>& r, int first, T min_dist, T max_dist, T* t_out,
-                                           int* prim_out) {
+__device__ __forceinline__ bool block6_hit(const DScene<T>& S, const Ray<T>& r, int first, int block, T min_dist, T max_dist,
+                                           T* t_out, int* prim_out) {
+    // the six rects of the list are the faces of the box with these corners (checked when the scene is
+    // uploaded: same doubles, same comparisons), so 48 bytes stand for six 64-byte records
+    const DBlock<T> b = S.blocks[block];
     bool have = false;
     T bt = 0;
     int bi = -1;
-    rect_axis_test<T, 2>(S.rects[first + 0], first + 0, r, min_dist, max_dist, have, bt, bi);
-    rect_axis_test<T, 2>(S.rects[first + 1], first + 1, r, min_dist, max_dist, have, bt, bi);
-    rect_axis_test<T, 1>(S.rects[first + 2], first + 2, r, min_dist, max_dist, have, bt, bi);
-    rect_axis_test<T, 1>(S.rects[first + 3], first + 3, r, min_dist, max_dist, have, bt, bi);
-    rect_axis_test<T, 0>(S.rects[first + 4], first + 4, r, min_dist, max_dist, have, bt, bi);
-    rect_axis_test<T, 0>(S.rects[first + 5], first + 5, r, min_dist, max_dist, have, bt, bi);
+    rect_axis_test<T, 2>(block_face<T, 2>(b, false), first + 0, r, min_dist, max_dist, have, bt, bi);
+    rect_axis_test<T, 2>(block_face<T, 2>(b, true), first + 1, r, min_dist, max_dist, have, bt, bi);
+    rect_axis_test<T, 1>(block_face<T, 1>(b, false), first + 2, r, min_dist, max_dist, have, bt, bi);
+    rect_axis_test<T, 1>(block_face<T, 1>(b, true), first + 3, r, min_dist, max_dist, have, bt, bi);
+    rect_axis_test<T, 0>(block_face<T, 0>(b, false), first + 4, r, min_dist, max_dist, have, bt, bi);
+    rect_axis_test<T, 0>(block_face<T, 0>(b, true), first + 5, r, min_dist, max_dist, have, bt, bi);
     *t_out = bt;
     *prim_out = bi;
     return have;
@@ -662,7 +673,7 @@ __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& worl
     Ray<T> r = world_ray;
     if (ob.xform >= 0) r = to_object_space(rec<UNIFORM>(&S.xforms[ob.xform]), world_ray);
     if (ob.kind == RT_OBJ_RECTS) {
-        if (!UNIFORM && ob.block6) return block6_hit(S, r, ob.first, min_dist, max_dist, t_out, prim_out);
+        if (!UNIFORM && ob.block6) return block6_hit(S, r, ob.first, ob.block6 - 1, min_dist, max_dist, t_out, prim_out);
         return rects_hit<T, UNIFORM>(S, r, ob.first, ob.count, min_dist, max_dist, t_out, prim_out);
     }
     if constexpr ((FEAT & FEAT_SPHERES) != 0) {

@@ -98,8 +98,13 @@ struct alignas(16) DObject {
     int32_t kind, xform, first, count;
     int32_t world_index;
     int32_t dfs_rank;  // position of the object's leaf in the depth-first order of the world BVH (tie rule)
-    int32_t block6;    // RT_OBJ_RECTS with the six sides of a Block in Block::new's order (axes z, z, y, y, x, x)
+    int32_t block6;    // RT_OBJ_RECTS that are the six faces of one box (Block::new's order: axes z, z, y, y, x, x): 1 + index in DScene::blocks
     int32_t first4;    // RT_OBJ_BLAS: root in DScene::nodes4
+};
+
+template <typename T>
+struct alignas(16) DBlock {  // the two corners the six rects of a Block were made from
+    T lo[3], hi[3];
 };
 
 template <typename T>
@@ -131,6 +136,7 @@ struct DScene {
     const DNode2* nodes2;
     const DNode4* nodes4;  // world and mesh BVHs, four-wide (nullptr: walk nodes2)
     const DObject* objects;
+    const DBlock<T>* blocks;
     const DXform<T>* xforms;
     const DSphere<T>* spheres;
     const DMovingSphere<T>* moving_spheres;
