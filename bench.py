@@ -216,7 +216,7 @@ def main() -> None:
     # (ray 56 B + throughput 24 B + path id 4 B in f64) and writes one for every survivor; the
     # survivors of all launches are the rays of the later launches = rays - paths.
     fused = sum(s.shade_launches for s in stats) == 0 and n_extend > 0
-    kernel = "k_bounce" if fused else "k_extend"
+    kernel = "k_bounce" if fused else "k_extend_refill" if stats and stats[-1].extend_kernel == 1 else "k_extend"
     path_bytes = 84 if args.precision == "f64" else 44
     paths = float(sum(s.paths for s in stats))
     if fused:

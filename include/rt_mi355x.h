@@ -224,7 +224,8 @@ typedef struct rt_stats {
      * runs every bounce it is counted with ms_extend / extend_launches and these stay 0. */
     double ms_tail;       /* time inside tail launches */
     uint64_t rays_tail;   /* closest-hit queries issued inside tail launches (part of `rays`) */
-    uint32_t tail_launches, reserved;
+    uint32_t tail_launches;
+    uint32_t extend_kernel; /* which kernel ms_extend times: 0 k_extend, 1 k_extend_refill, 2 k_bounce (fused) */
 } rt_stats;
 
 /* Replaces the row closure of src/main.rs:124-137 (+ cast_ray, src/hitting.rs:11-31) for

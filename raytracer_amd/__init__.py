@@ -52,7 +52,7 @@ class RtStats(C.Structure):
         ("rays", C.c_uint64), ("paths", C.c_uint64), ("ms_total", C.c_double), ("ms_extend", C.c_double),
         ("ms_shade", C.c_double), ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32),
         ("batches", C.c_uint32), ("max_depth_reached", C.c_uint32),
-        ("ms_tail", C.c_double), ("rays_tail", C.c_uint64), ("tail_launches", C.c_uint32), ("reserved", C.c_uint32),
+        ("ms_tail", C.c_double), ("rays_tail", C.c_uint64), ("tail_launches", C.c_uint32), ("extend_kernel", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:

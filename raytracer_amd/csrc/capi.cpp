@@ -824,6 +824,7 @@ struct Engine : EngineBase {
         if (stats) {
             stats->rays = totals[0] + totals[1];
             if (!fused) stats->rays_tail = tail_first_bounce + totals[1];
+            stats->extend_kernel = fused ? 2u : refill_lanes() > 0 ? 1u : 0u;
             stats->paths = npix * ns;
             stats->batches = n_batches;
             stats->max_depth_reached = deepest;
@@ -1055,6 +1056,7 @@ int rt_render_rows(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0
                 stats->ms_total += part.ms_total; stats->ms_extend += part.ms_extend; stats->ms_shade += part.ms_shade;
                 stats->extend_launches += part.extend_launches; stats->shade_launches += part.shade_launches;
                 stats->ms_tail += part.ms_tail; stats->rays_tail += part.rays_tail; stats->tail_launches += part.tail_launches;
+                stats->extend_kernel = part.extend_kernel;
                 stats->batches += part.batches;
                 stats->max_depth_reached = std::max(stats->max_depth_reached, part.max_depth_reached);
             }

@@ -24,7 +24,7 @@ for scene in ("cornell", "knight", "blocks_ball"):
             if r["Counter_Name"] != counter:
                 continue
             k = r["Kernel_Name"]
-            name = "k_bounce" if "k_bounce" in k else "k_extend" if "k_extend" in k else None
+            name = "k_bounce" if "k_bounce" in k else "k_extend_refill" if "k_extend_refill" in k else "k_extend" if "k_extend" in k else None
             if name:
                 agg[name] += float(r["Counter_Value"])
                 n[name] += 1
@@ -32,7 +32,7 @@ for scene in ("cornell", "knight", "blocks_ball"):
     if len(per) < 2:
         continue
     # the kernel that runs every bounce (a single k_bounce next to many k_extend launches is the tail launch)
-    kernel = "k_bounce" if per["fetch"][1]["k_bounce"] > per["fetch"][1]["k_extend"] else "k_extend"
+    kernel = max(("k_bounce", "k_extend", "k_extend_refill"), key=lambda name: per["fetch"][1][name])
     launches = per["fetch"][1][kernel]
     fetch = per["fetch"][0][kernel] * 1024.0 * 2.0 / launches
     write = per["write"][0][kernel] * 1024.0 / per["write"][1][kernel]
