@@ -73,13 +73,13 @@ def measured_traffic(scene_name: str, prec: str, kernel: str = None):
     return None
 
 
-def cpu_baseline(scene_path: str, width: int, bounces: int, seed: int) -> dict:
+def cpu_baseline(scene_path: str, width: int, bounces: int, seed: int, asset_root: str = ROOT) -> dict:
     """CPU oracle on a bounded sample of the workload: same scene / width / bounces, fewer
     samples per pixel (rays per sample are the same in expectation)."""
     from oracle import binding as orc
 
     threads = max(1, min(16, os.cpu_count() or 1))
-    sc = orc.OracleScene.load(scene_path, ROOT)
+    sc = orc.OracleScene.load(scene_path, asset_root)
     H = sc.image_height(width)
     spp = 1
     t0 = time.time()
@@ -107,6 +107,9 @@ def main() -> None:
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--triangles", type=int, default=0,
+                    help="--scene knight only: generate the stand-in mesh with about this many triangles in a scratch "
+                         "directory (default: the ~100 k-triangle examples/knight.obj; BASELINE configs[4] names ~1 M)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --spp is the whole image's sample count, split over the GPUs (default: weak, --spp per GPU)")
     args = ap.parse_args()
@@ -132,12 +135,23 @@ def main() -> None:
         dist = dist_mod
 
     scene_path = os.path.join(ROOT, "examples", args.scene + ".json5")
+    asset_root = ROOT
     if args.scene == "knight":
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import gen_knight
 
-        gen_knight.ensure(os.path.join(ROOT, "examples", "knight.obj"))
-    scene = rt.Scene.load(scene_path, ROOT)
+        if args.triangles > 0:  # another size of the stand-in, one copy per rank, outside the tree
+            import shutil
+            import tempfile
+
+            asset_root = tempfile.mkdtemp(prefix="knight_")
+            os.makedirs(os.path.join(asset_root, "examples"))
+            gen_knight.ensure(os.path.join(asset_root, "examples", "knight.obj"), args.triangles)
+            shutil.copy(scene_path, os.path.join(asset_root, "examples", "knight.json5"))
+            scene_path = os.path.join(asset_root, "examples", "knight.json5")
+        else:
+            gen_knight.ensure(os.path.join(ROOT, "examples", "knight.obj"))
+    scene = rt.Scene.load(scene_path, asset_root)
     W = args.width
     H = scene.image_height(W)
     npix = W * H
@@ -246,7 +260,7 @@ def main() -> None:
         "config": {
             "workload": f"examples/{args.scene}.json5 {W}x{H}, {total_spp // world if args.strong else args.spp} spp per GPU ({total_spp} spp image), "
                         f"{args.bounces} bounces, sample-split across {world} GPU(s), reduce to rank 0, quantise",
-            "paths_per_step": npix * total_spp, "rays_per_step": rays_all / args.steps,
+            "triangles": scene.counts()["triangles"], "paths_per_step": npix * total_spp, "rays_per_step": rays_all / args.steps,
             "wall_clock_per_image_s": dt / args.steps, "seed": args.seed,
         },
         "roofline": {
@@ -264,7 +278,7 @@ def main() -> None:
                               "gpu_total": float(t[5]) / args.steps},
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(scene_path, W, args.bounces, args.seed)
+        out["cpu_baseline"] = cpu_baseline(scene_path, W, args.bounces, args.seed, asset_root)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
