@@ -448,6 +448,7 @@ struct Engine : EngineBase {
                 v[i].param = (T)m.param;
                 v[i].type = m.type; v[i].image = m.image; v[i].odd = m.odd; v[i].even = m.even;
             }
+            bool any_checker_emits = false;
             // Checkered: `image` (unused by that type) says whether some part of it, through nested checkers,
             // is a light; emitted() of any other checker is black whatever part (u, v) selects.
             for (size_t i = 0; i < v.size(); i++) {
@@ -468,8 +469,12 @@ struct Engine : EngineBase {
                     }
                 }
                 v[i].image = emits ? 1 : 0;
+                if (emits) any_checker_emits = true;
             }
             materials.upload(v);
+            // Light and sky are where paths end (DiffuseLight::scatter is None, src/materials.rs:126-128); only a
+            // checker may emit through one part and scatter through another (the PI asymmetry, :166-183).
+            S.emit_once = any_checker_emits ? 0 : 1;
         }
         {
             std::vector<rtd::DImage> v(d.n_images);

@@ -156,7 +156,7 @@ struct DScene {
     int32_t tlas_root4;  // world BVH in nodes4 (valid when nodes4 != nullptr)
     int32_t stack_cap;   // > 0: entries of the LDS stack a four-wide walk may use before it overflows (tests)
     int32_t has_meshes, has_media;  // object kinds present: pick the four-wide kernel compiled for them
-    int32_t pad_[1];
+    int32_t emit_once;  // no checker has a light among its parts: a path adds to its sample at most once, when it ends (plain store)
     DCamera<T> camera;
     DSky<T> sky;
 };

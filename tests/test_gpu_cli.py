@@ -3,6 +3,7 @@ monitor thread, .PART files, image output) over the C ABI.  The image it writes 
 library's own render of the same seed (bit-exact) and the oracle's (>= 99 % of the bytes)."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -93,3 +94,43 @@ def test_cli_recovers_rows_from_a_part_file(tmp_path):
         assert np.array_equal(c[H - 1 - j], want[H - 1 - j]), f"row j={j}"
     # the recovered file is left alone, the new part file (c.ppm.1.PART) is gone
     assert sorted(os.listdir(tmp_path)) == ["a.ppm", "b.ppm", "c.ppm", "c.ppm.0.PART"]
+
+
+def _render_py(tmp_path, *extra, seed=5, out="py.ppm"):
+    r = subprocess.run([sys.executable, "-m", "raytracer_amd.render", SCENE, out, "-w", str(W), "-s", str(SPP), "-m", str(MB),
+                        "--seed", str(seed), *extra], capture_output=True, cwd=tmp_path, timeout=110,
+                       env={**os.environ, "PYTHONPATH": ROOT})
+    assert r.returncode == 0, r.stderr.decode()
+    return _read_ppm(os.path.join(tmp_path, out)), r
+
+
+def test_node_render_driver_is_the_cli_on_one_gpu(tmp_path):
+    """python -m raytracer_amd.render (the N-GPU driver: bands, sample split, reduce, .PART records) with one
+    rank writes the picture bin/raytracer writes, recovers rows from a part file and leaves none behind."""
+    import raytracer_amd as rt
+
+    a, _ = _render(tmp_path, seed=1, out="a.ppm")
+    b, r = _render_py(tmp_path, "--band-rows", "5", "--progress-bar-len", "40", "--stats", seed=1, out="b.ppm")
+    assert np.array_equal(a, b)
+    err = r.stderr.decode()
+    assert "Rendering: [" in err and "Completed in 0:" in err and "rays on 1 GPU(s)" in err
+    other, _ = _render(tmp_path, seed=2, out="other.ppm")
+    kept = list(range(47, 41, -1)) + list(range(30, 20, -1)) + [0]
+    old = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        pf = rt.PartFile("c.ppm", W, H)
+        for j in kept:
+            pf.write(j, other[H - 1 - j])
+        pf.finish(remove=False)
+    finally:
+        os.chdir(old)
+    c, r = _render_py(tmp_path, "-r", pf.path, "--band-rows", "4", "-q", seed=1, out="c.ppm")
+    assert b"Rendering" not in r.stderr and b"Completed" not in r.stderr  # (the ROCm runtime may print a line of its own)
+    for j in range(H):
+        want = other if j in kept else a
+        assert np.array_equal(c[H - 1 - j], want[H - 1 - j]), f"row j={j}"
+    assert sorted(os.listdir(tmp_path)) == ["a.ppm", "b.ppm", "c.ppm", "c.ppm.0.PART", "other.ppm"]
+    bad = subprocess.run([sys.executable, "-m", "raytracer_amd.render", SCENE, "d.ppm", "-w", str(W), "-r", "missing.PART"],
+                         capture_output=True, cwd=tmp_path, timeout=110, env={**os.environ, "PYTHONPATH": ROOT})
+    assert bad.returncode == 1 and b"Error:" in bad.stderr and "d.ppm" not in os.listdir(tmp_path)
