@@ -925,13 +925,18 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
     return have;
 }
 
+// Returned by value (in registers): with out-parameters the caller's whole Surface had to live in scratch
+// memory, and its stores and reloads were HBM traffic in every kernel that can shade a sphere.
 template <typename T>
-__device__ __noinline__ void get_sphere_uv(V3<T> p, T* u, T* v) {  // src/math.rs:288-294
+struct UV {
+    T u, v;
+};
+template <typename T>
+__device__ __noinline__ UV<T> get_sphere_uv(V3<T> p) {  // src/math.rs:288-294
     const T PI = (T)3.14159265358979323846264338327950288;
     T theta = acos(-p.y);
     T phi = atan2(-p.z, p.x) + PI;
-    *u = phi / ((T)2.0 * PI);
-    *v = theta / PI;
+    return UV<T>{phi / ((T)2.0 * PI), theta / PI};
 }
 
 template <typename T>
@@ -1000,13 +1005,21 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
     } else if ((FEAT & FEAT_SPHERES) != 0 && kind == RT_OBJ_SPHERE) {
         const DSphere<T>& s = S.spheres[w.prim];
         outward = (r.at(t) - ld3(s.centre)) / s.radius;
-        if (want_uv) get_sphere_uv(outward, &sf.u, &sf.v);
+        if (want_uv) {
+            const UV<T> uv = get_sphere_uv(outward);
+            sf.u = uv.u;
+            sf.v = uv.v;
+        }
         sf.material = s.material;
         sf.owner = s.owner;
     } else if ((FEAT & FEAT_SPHERES) != 0 && kind == RT_OBJ_MOVING_SPHERE) {
         const DMovingSphere<T>& s = S.moving_spheres[w.prim];
         outward = (r.at(t) - moving_centre(s, r.time)) / s.radius;
-        if (want_uv) get_sphere_uv(outward, &sf.u, &sf.v);
+        if (want_uv) {
+            const UV<T> uv = get_sphere_uv(outward);
+            sf.u = uv.u;
+            sf.v = uv.v;
+        }
         sf.material = s.material;
         sf.owner = s.owner;
     } else if ((FEAT & (FEAT_FLAT | FEAT_BLAS)) != 0 && (kind == RT_OBJ_TRIANGLE || kind == RT_OBJ_BLAS)) {
@@ -1692,7 +1705,10 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene<T> S, DBatch B, DQueue<T
 
 // extend + shade of one bounce in one kernel (the render path): the hit record never leaves the
 // registers, the ray is read once, and a bounce is one launch.  rt_trace keeps k_extend.
-template <typename T, int STACK, int MODE>
+// CAN_TAIL = false: compiled for per-bounce launches only (the sweep kernels, which run every bounce of
+// cornell-like scenes): the bounce loop, its counters and the second ray are gone, and with them the last
+// register spills of the lean kernel.
+template <typename T, int STACK, int MODE, bool CAN_TAIL>
 __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_bounce(DScene<T> S, DSmallScene small, DBatch B, DQueue<T> qin, DQueue<T> qout,
                                                                     T* sample_rgb, uint32_t depth0, uint32_t max_bounces,
                                                                     const uint32_t* __restrict__ tile_offsets,
@@ -1706,7 +1722,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_bounce(DScene<T> S, 
     // its own pace (a launch per bounce would wait for the slowest ray of every bounce: on the knight
     // ~0.4 ms per bounce for a ray caught inside the glass mesh, 35 times over).  Same streams, same
     // arithmetic, same image.
-    const bool run_tail = tail.ray_total != nullptr;
+    const bool run_tail = CAN_TAIL && tail.ray_total != nullptr;
     uint32_t extra_queries = 0, deepest = depth0;
     DScene<T> W = S;  // the traversal's view of the scene (records in LDS for small worlds)
     if (LDS_SCENE) stage_small_scene(W, small, lds_scene);
@@ -1902,12 +1918,18 @@ void Launch<T>::bounce(const DScene<T>& S, const DSmallScene& small, const DBatc
                        uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets, uint32_t* tile_counts_out,
                        uint32_t n_tiles, int stack, int grid_blocks, const DTail* tail, hipStream_t st) {
     const DTail tl = tail ? *tail : DTail{nullptr, nullptr};
-#define RT_BOUNCE(STACK, MODE)                                                                                            \
-    hipLaunchKernelGGL((k_bounce<T, STACK, MODE>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, qin, qout, sample_rgb, \
+#define RT_BOUNCE_(STACK, MODE, CAN_TAIL)                                                                                 \
+    hipLaunchKernelGGL((k_bounce<T, STACK, MODE, CAN_TAIL>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, qin, qout, sample_rgb, \
                        depth, max_bounces, tile_offsets, tile_counts_out, n_tiles, tl)
-    if (S.n_sweep > 0 && S.lean) RT_BOUNCE(1, WALK_SWEEP_LEAN);
-    else if (S.n_sweep > 0 && stack <= 16) RT_BOUNCE(16, WALK_SWEEP);
-    else if (S.n_sweep > 0) RT_BOUNCE(64, WALK_SWEEP);
+#define RT_BOUNCE(STACK, MODE) RT_BOUNCE_(STACK, MODE, true)
+#define RT_BOUNCE_SWEEP(STACK, MODE)              \
+    do {                                          \
+        if (tail) RT_BOUNCE_(STACK, MODE, true);  \
+        else RT_BOUNCE_(STACK, MODE, false);      \
+    } while (0)
+    if (S.n_sweep > 0 && S.lean) RT_BOUNCE_SWEEP(1, WALK_SWEEP_LEAN);
+    else if (S.n_sweep > 0 && stack <= 16) RT_BOUNCE_SWEEP(16, WALK_SWEEP);
+    else if (S.n_sweep > 0) RT_BOUNCE_SWEEP(64, WALK_SWEEP);
     else if (small.blob && stack <= 16) RT_BOUNCE(16, WALK_OWN_BOX_LDS);
 #define RT_BOUNCE4(MODE)                       \
     do {                                       \
@@ -1923,7 +1945,9 @@ void Launch<T>::bounce(const DScene<T>& S, const DSmallScene& small, const DBatc
     else if (stack <= 16) RT_BOUNCE(16, WALK_NODE2);
     else if (stack <= 32) RT_BOUNCE(32, WALK_NODE2);
     else RT_BOUNCE(64, WALK_NODE2);
+#undef RT_BOUNCE_SWEEP
 #undef RT_BOUNCE
+#undef RT_BOUNCE_
 }
 template <typename T>
 void Launch<T>::shade(const DScene<T>& S, const DBatch& B, DQueue<T> qin, DHits<T> h, DQueue<T> qout, T* sample_rgb,
