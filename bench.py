@@ -182,6 +182,8 @@ def main() -> None:
         if collect is not None:
             collect.append(st)
 
+    if dist is not None:  # RCCL sets its connections up in the first collective of each kind: not a step, never timed
+        parallel.reduce_to_root(torch.zeros(1024, dtype=torch.float64, device=dev), dist)
     for _ in range(args.warmup):
         step(None)
     stats = []
@@ -265,7 +267,8 @@ def main() -> None:
         },
         "roofline": {
             "bound": "hbm", "kernel": kernel, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(args.scene, args.precision, kernel),
+            "frac": achieved_gbs / HBM_PEAK_GBS,
+            "traffic": None if args.triangles > 0 else measured_traffic(args.scene, args.precision, kernel),  # PMC passes exist for the default meshes only
             "bytes_per_launch": bytes_per_launch, "bytes_per_ray": bytes_per_ray, "scene_bytes": scene_bytes,
             "launches": n_extend, "avg_launch_ms": ms_per_launch, "rays_per_launch": rays_per_launch,
             "touched": {"bytes_per_ray": touched_bpr, "achieved_GBps": touched_gbs,

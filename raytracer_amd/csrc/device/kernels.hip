@@ -1061,6 +1061,9 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
 
 // ------------------------------------------------------------------ kernels
 constexpr int BLOCK = 256;
+#ifndef RT_TAIL_WAVES
+#define RT_TAIL_WAVES 2
+#endif
 template <int MODE, bool DEEP = walks_node4(MODE)> struct StackFor {
     typedef Stack type;
     static constexpr int SPILL = 1;
@@ -1708,8 +1711,10 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene<T> S, DBatch B, DQueue<T
 // CAN_TAIL = false: compiled for per-bounce launches only (the sweep kernels, which run every bounce of
 // cornell-like scenes): the bounce loop, its counters and the second ray are gone, and with them the last
 // register spills of the lean kernel.
+// CAN_TAIL = true is the tail launch in the product (a few thousand waves, fewer than two per SIMD): it is
+// compiled for 2 waves per SIMD, i.e. up to 256 VGPRs, so that the walk + shading of a tree scene does not spill.
 template <typename T, int STACK, int MODE, bool CAN_TAIL>
-__global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_bounce(DScene<T> S, DSmallScene small, DBatch B, DQueue<T> qin, DQueue<T> qout,
+__global__ void __launch_bounds__(BLOCK, CAN_TAIL ? RT_TAIL_WAVES : RT_EXTEND_WAVES) k_bounce(DScene<T> S, DSmallScene small, DBatch B, DQueue<T> qin, DQueue<T> qout,
                                                                     T* sample_rgb, uint32_t depth0, uint32_t max_bounces,
                                                                     const uint32_t* __restrict__ tile_offsets,
                                                                     uint32_t* tile_counts_out, uint32_t n_tiles, DTail tail) {
