@@ -665,7 +665,9 @@ struct Engine : EngineBase {
     int grid_for(size_t n) {  // persistent blocks, grid-stride over the dense work index
         size_t blocks = (n + 255) / 256;
         size_t cap = (size_t)num_cus * 8;
-        return (int)(blocks < 1 ? 1 : blocks > cap ? cap : blocks);
+        blocks = blocks < 1 ? 1 : blocks > cap ? cap : blocks;
+        if (blocks > 8) blocks = (blocks + 7) & ~(size_t)7;  // whole groups of eight: k_extend's XCD-aware chunk order (a block without work leaves at once)
+        return (int)blocks;
     }
     void need_scene() {
         if (!have_scene) throw RtError{RT_ERR_NO_SCENE, "no scene uploaded (call rt_upload_scene first)"};

@@ -1061,6 +1061,10 @@ __device__ Surface<T> make_surface(const DScene<T>& S, const Ray<T>& world_ray, 
 
 // ------------------------------------------------------------------ kernels
 constexpr int BLOCK = 256;
+#ifndef RT_XCD_RUN
+#define RT_XCD_RUN 16  // chunks of 256 rays per run of k_extend's XCD-aware order (16 = one 4096-slot tile); 0: every eighth chunk
+#endif
+#define RT_XCD_RUN_ (RT_XCD_RUN > 0 ? (uint32_t)RT_XCD_RUN : 1u)
 #ifndef RT_TAIL_WAVES
 #define RT_TAIL_WAVES 2
 #endif
@@ -1208,7 +1212,16 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
     if (LDS_SCENE) stage_small_scene(S, small, lds_scene);
     const uint32_t total = tile_offsets[n_tiles];
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < total; base += gridDim.x * BLOCK) {
+    // XCD-aware order of the 256-ray chunks (RT_XCD_RUN > 0): the blocks that share an XCD (blockIdx % 8) take
+    // runs of RT_XCD_RUN consecutive chunks, dealt round-robin to the eight groups, instead of every eighth
+    // chunk.  Consecutive chunks hold neighbouring pixels' paths, so the rays an XCD has in flight at a time
+    // come from an eighth as many image rows, and its 4 MB L2 has an eighth of the nodes and triangles to hold.
+    const bool xcd_order = RT_XCD_RUN > 0 && (gridDim.x & 7u) == 0;
+    const uint32_t chunk_step = xcd_order ? gridDim.x >> 3 : gridDim.x;
+    for (uint32_t m = xcd_order ? blockIdx.x >> 3 : blockIdx.x;; m += chunk_step) {
+        const uint32_t chunk = xcd_order ? ((m / RT_XCD_RUN_) * 8u + (blockIdx.x & 7u)) * RT_XCD_RUN_ + m % RT_XCD_RUN_ : m;
+        if (chunk * BLOCK >= total) break;  // chunk grows with m in either order
+        const uint32_t base = chunk * BLOCK + (threadIdx.x & ~63u);
         const uint32_t d = base + lane;
         if (d >= total) continue;
         uint32_t tile;
@@ -1223,7 +1236,9 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
             Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(S, r, t, w, S.needs_uv != 0 || h.owner != nullptr);
             h.t[i] = t;
             h.nx[i] = sf.normal.x; h.ny[i] = sf.normal.y; h.nz[i] = sf.normal.z;
-            h.u[i] = sf.u; h.v[i] = sf.v;
+            if (S.needs_uv != 0 || h.owner != nullptr) {  // nobody reads (u, v) otherwise: 16 B per hit not written, not read
+                h.u[i] = sf.u; h.v[i] = sf.v;
+            }
             h.mat_front[i] = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
             if (h.owner) {
                 h.owner[i] = sf.owner;
@@ -1410,7 +1425,9 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend_refill(DScene
                     Surface<T> sf = make_surface<T, FEAT>(S, walk.ray, best_t, best, S.needs_uv != 0 || h.owner != nullptr);
                     h.t[i] = best_t;
                     h.nx[i] = sf.normal.x; h.ny[i] = sf.normal.y; h.nz[i] = sf.normal.z;
-                    h.u[i] = sf.u; h.v[i] = sf.v;
+                    if (S.needs_uv != 0 || h.owner != nullptr) {
+                        h.u[i] = sf.u; h.v[i] = sf.v;
+                    }
                     h.mat_front[i] = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
                     if (h.owner) {
                         h.owner[i] = sf.owner;
@@ -1672,8 +1689,11 @@ __device__ __forceinline__ void compact_store(bool alive, uint32_t tile, const R
     }
 }
 
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 1
+#endif
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_shade(DScene<T> S, DBatch B, DQueue<T> qin, DHits<T> h, DQueue<T> qout,
+__global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DScene<T> S, DBatch B, DQueue<T> qin, DHits<T> h, DQueue<T> qout,
                                                   T* sample_rgb, uint32_t depth, uint32_t max_bounces,
                                                   const uint32_t* __restrict__ tile_offsets, uint32_t* tile_counts_out,
                                                   uint32_t n_tiles) {
@@ -1697,7 +1717,10 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene<T> S, DBatch B, DQueue<T
             T t = 0, u = 0, v = 0;
             V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
             if (mf != RT_MISS) {
-                t = h.t[i]; u = h.u[i]; v = h.v[i];
+                t = h.t[i];
+                if (S.needs_uv) {
+                    u = h.u[i]; v = h.v[i];
+                }
                 n = mk(h.nx[i], h.ny[i], h.nz[i]);
             }
             alive = shade_path(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
