@@ -74,8 +74,11 @@ struct alignas(16) DRect {
     int32_t axis, facing_positive, material, owner, sub, pad;
 };
 
+#ifndef RT_TRI_ALIGN
+#define RT_TRI_ALIGN 16
+#endif
 template <typename T>
-struct alignas(16) DTriangle {
+struct alignas(sizeof(T) == 8 ? RT_TRI_ALIGN : 16) DTriangle {
     T point[3], vec1[3], vec2[3], normal[3];
     int32_t material, owner, sub;
     int32_t dfs_rank;  // position of the triangle's leaf in the depth-first order of its mesh BVH (tie rule)
