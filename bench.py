@@ -95,6 +95,52 @@ def cpu_baseline(scene_path: str, width: int, bounces: int, seed: int, asset_roo
                       f"{rays} rays in {dt:.2f} s; C++ f64 restatement of the reference renderer (oracle/), {threads} threads"}
 
 
+class MergedStats:
+    """rt_stats of the concurrent batches of one step: counts and per-stream launch times added up (the streams run at
+    the same time, so the stage times add up to more than the step takes)."""
+
+    def __init__(self, parts):
+        for f in ("rays", "paths", "rays_tail", "ms_extend", "ms_shade", "ms_tail", "extend_launches", "shade_launches", "tail_launches"):
+            setattr(self, f, sum(getattr(p, f) for p in parts))
+        self.ms_total = max(p.ms_total for p in parts)
+        self.extend_kernel = parts[-1].extend_kernel
+
+
+def render_overlapped(renderers, accums, W, H, s0, ns, bounces, seed):
+    """The rank's sample range as len(renderers) concurrent batches, each through its own context (stream) from its own
+    host thread (ctypes releases the GIL inside the call); the partial sums are added into accums[0]."""
+    import threading
+
+    import torch
+
+    from raytracer_amd import parallel
+
+    K = len(renderers)
+    for a in accums[1:]:
+        a.zero_()
+    torch.cuda.synchronize()
+    parts = [None] * K
+    errors = []
+
+    def work(k):
+        try:
+            b0, bn = parallel.split_samples(ns, K, k, first_sample=s0)
+            parts[k] = renderers[k].render_accum_device(W, H, 0, H, b0, bn, bounces, seed, accums[k].data_ptr(), want_stats=True)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(K)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    for a in accums[1:]:
+        accums[0] += a
+    return MergedStats(parts)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +156,9 @@ def main() -> None:
     ap.add_argument("--triangles", type=int, default=0,
                     help="--scene knight only: generate the stand-in mesh with about this many triangles in a scratch "
                          "directory (default: the ~100 k-triangle examples/knight.obj; BASELINE configs[4] names ~1 M)")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="render a rank's samples as this many concurrent batches (one context = one stream and one host thread each) "
+                         "so that one batch's latency-bound late bounces run under another's early ones (DESIGN.md section 7; default 1: off)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --spp is the whole image's sample count, split over the GPUs (default: weak, --spp per GPU)")
     args = ap.parse_args()
@@ -155,12 +204,18 @@ def main() -> None:
     W = args.width
     H = scene.image_height(W)
     npix = W * H
-    renderer = rt.Renderer(device=local_rank, precision=rt.PRECISION_F64 if args.precision == "f64" else rt.PRECISION_F32,
-                           max_paths=1 << 26)
-    renderer.upload(scene)
+    K = max(1, args.overlap)
+    renderers = []
+    for _ in range(K):
+        r = rt.Renderer(device=local_rank, precision=rt.PRECISION_F64 if args.precision == "f64" else rt.PRECISION_F32,
+                        max_paths=(1 << 26) // K)
+        r.upload(scene)
+        renderers.append(r)
+    renderer = renderers[0]
 
     dev = torch.device("cuda", local_rank)
     accum = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
+    extra_accum = [torch.zeros(npix * 3, dtype=torch.float64, device=dev) for _ in range(K - 1)]
     rgb8 = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
     total_spp = args.spp if args.strong else args.spp * world
     s0, ns = parallel.split_samples(total_spp, world, rank)
@@ -174,7 +229,10 @@ def main() -> None:
     def step(collect):
         accum.zero_()
         torch.cuda.synchronize()  # torch's stream -> the library's stream hand-off
-        st = renderer.render_accum_device(W, H, 0, H, s0, ns, args.bounces, args.seed, accum.data_ptr(), want_stats=True)
+        if K == 1:
+            st = renderer.render_accum_device(W, H, 0, H, s0, ns, args.bounces, args.seed, accum.data_ptr(), want_stats=True)
+        else:
+            st = render_overlapped(renderers, [accum] + extra_accum, W, H, s0, ns, args.bounces, args.seed)
         parallel.reduce_to_root(accum, dist)
         if rank == 0:
             torch.cuda.synchronize()
@@ -263,7 +321,7 @@ def main() -> None:
             "workload": f"examples/{args.scene}.json5 {W}x{H}, {total_spp // world if args.strong else args.spp} spp per GPU ({total_spp} spp image), "
                         f"{args.bounces} bounces, sample-split across {world} GPU(s), reduce to rank 0, quantise",
             "triangles": scene.counts()["triangles"], "paths_per_step": npix * total_spp, "rays_per_step": rays_all / args.steps,
-            "wall_clock_per_image_s": dt / args.steps, "seed": args.seed,
+            "wall_clock_per_image_s": dt / args.steps, "seed": args.seed, "concurrent_batches_per_gpu": K,
         },
         "roofline": {
             "bound": "hbm", "kernel": kernel, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
