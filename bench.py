@@ -106,41 +106,6 @@ class MergedStats:
         self.extend_kernel = parts[-1].extend_kernel
 
 
-def render_overlapped(renderers, accums, W, H, s0, ns, bounces, seed):
-    """The rank's sample range as len(renderers) concurrent batches, each through its own context (stream) from its own
-    host thread (ctypes releases the GIL inside the call); the partial sums are added into accums[0]."""
-    import threading
-
-    import torch
-
-    from raytracer_amd import parallel
-
-    K = len(renderers)
-    for a in accums[1:]:
-        a.zero_()
-    torch.cuda.synchronize()
-    parts = [None] * K
-    errors = []
-
-    def work(k):
-        try:
-            b0, bn = parallel.split_samples(ns, K, k, first_sample=s0)
-            parts[k] = renderers[k].render_accum_device(W, H, 0, H, b0, bn, bounces, seed, accums[k].data_ptr(), want_stats=True)
-        except Exception as e:  # noqa: BLE001
-            errors.append(e)
-
-    threads = [threading.Thread(target=work, args=(k,)) for k in range(K)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
-    for a in accums[1:]:
-        accums[0] += a
-    return MergedStats(parts)
-
-
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,7 +197,7 @@ def main() -> None:
         if K == 1:
             st = renderer.render_accum_device(W, H, 0, H, s0, ns, args.bounces, args.seed, accum.data_ptr(), want_stats=True)
         else:
-            st = render_overlapped(renderers, [accum] + extra_accum, W, H, s0, ns, args.bounces, args.seed)
+            st = MergedStats(parallel.render_concurrent(renderers, [accum] + extra_accum, W, H, 0, H, s0, ns, args.bounces, args.seed))
         parallel.reduce_to_root(accum, dist)
         if rank == 0:
             torch.cuda.synchronize()

@@ -40,7 +40,8 @@ from . import parallel
 class GpuEngine:
     """One rank's GPU renderer behind the C ABI (include/rt_mi355x.h)."""
 
-    def __init__(self, scene_path: str, device: int, precision: str = "f64", max_paths: int = 0, asset_root: Optional[str] = None):
+    def __init__(self, scene_path: str, device: int, precision: str = "f64", max_paths: int = 0, asset_root: Optional[str] = None,
+                 overlap: int = 1):
         import torch
 
         import raytracer_amd as rt
@@ -49,9 +50,14 @@ class GpuEngine:
         self.scene = rt.Scene.load(scene_path, asset_root)
         torch.cuda.set_device(device)
         self.device = torch.device("cuda", device)
-        self.renderer = rt.Renderer(device=device, precision=rt.PRECISION_F64 if precision == "f64" else rt.PRECISION_F32,
-                                    max_paths=max_paths)
-        self.renderer.upload(self.scene)
+        # overlap > 1: that many contexts (streams) on this GPU, a band's samples split over them and rendered
+        # concurrently (parallel.render_concurrent)
+        self.renderers = []
+        for _ in range(max(1, overlap)):
+            r = rt.Renderer(device=device, precision=rt.PRECISION_F64 if precision == "f64" else rt.PRECISION_F32, max_paths=max_paths)
+            r.upload(self.scene)
+            self.renderers.append(r)
+        self.renderer = self.renderers[0]
         self.rays = 0
         self.gpu_ms = 0.0
 
@@ -61,13 +67,13 @@ class GpuEngine:
     def render_band(self, width: int, height: int, lo: int, hi: int, s0: int, n: int, max_bounces: int, seed: int):
         """f64 radiance sums of rows [lo, hi) over samples [s0, s0 + n): a device tensor of (hi-lo)*width*3."""
         torch = self.torch
-        accum = torch.zeros((hi - lo) * width * 3, dtype=torch.float64, device=self.device)
+        accums = [torch.zeros((hi - lo) * width * 3, dtype=torch.float64, device=self.device) for _ in self.renderers]
         if n > 0:
-            torch.cuda.synchronize(self.device)  # torch's stream -> the library's stream
-            st = self.renderer.render_accum_device(width, height, lo, hi, s0, n, max_bounces, seed, accum.data_ptr())
-            self.rays += st.rays
-            self.gpu_ms += st.ms_total
-        return accum
+            torch.cuda.synchronize(self.device)  # torch's stream -> the library's streams
+            parts = parallel.render_concurrent(self.renderers, accums, width, height, lo, hi, s0, n, max_bounces, seed)
+            self.rays += sum(st.rays for st in parts)
+            self.gpu_ms += max(st.ms_total for st in parts)
+        return accums[0]
 
     def quantize(self, accum, n_pixels: int, spp: int) -> np.ndarray:
         torch = self.torch
@@ -245,6 +251,8 @@ def main(argv=None) -> int:
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--band-rows", type=int, default=0)
     ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="concurrent batches per GPU (2: about 12 %% faster; the picture may differ from --overlap 1 in the last bit of a sum)")
     args = ap.parse_args(argv)
 
     import torch
@@ -267,7 +275,7 @@ def main(argv=None) -> int:
     start = time.monotonic()
     rc = 0
     try:
-        engine = GpuEngine(args.input_file, local_rank, args.precision)
+        engine = GpuEngine(args.input_file, local_rank, args.precision, overlap=args.overlap)
         seed = args.seed
         if seed is None:  # one seed for the whole job, drawn on rank 0
             seed = int.from_bytes(os.urandom(8), "little") >> 1

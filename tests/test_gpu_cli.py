@@ -134,3 +134,6 @@ def test_node_render_driver_is_the_cli_on_one_gpu(tmp_path):
     bad = subprocess.run([sys.executable, "-m", "raytracer_amd.render", SCENE, "d.ppm", "-w", str(W), "-r", "missing.PART"],
                          capture_output=True, cwd=tmp_path, timeout=110, env={**os.environ, "PYTHONPATH": ROOT})
     assert bad.returncode == 1 and b"Error:" in bad.stderr and "d.ppm" not in os.listdir(tmp_path)
+    # two concurrent half-batches per GPU: the same picture up to the order of two f64 additions per sum
+    e, _ = _render_py(tmp_path, "--overlap", "2", "-q", "--no-part-file", seed=1, out="e.ppm")
+    assert np.abs(e.astype(int) - a.astype(int)).max() <= 1 and (e != a).mean() <= 1e-3
