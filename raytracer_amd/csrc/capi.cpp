@@ -759,6 +759,9 @@ struct Engine : EngineBase {
         const bool fused = fuse_env ? fuse_env[0] != '0' : (S.n_sweep > 0 && S.lean);
         // Paths alive at or below which the tail launch takes over (RT_TAIL=n in the environment overrides, 0: never);
         // measured: knight 78.8 / 69.0 / 67.0 / 68.5 ms at 0 / 64 k / 128 k / 600 k, cornell 24.85 / 24.7 / 24.4 / 24.2
+        // The host looks at the live count every peek_every-th bounce (RT_PEEK=n in the environment overrides).
+        uint32_t peek_every = 4;
+        if (const char* e = std::getenv("RT_PEEK")) peek_every = (uint32_t)std::max(1l, std::strtol(e, nullptr, 10));
         uint32_t tail_threshold = fused ? 524288u : 131072u;
         if (const char* e = std::getenv("RT_TAIL")) tail_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
         std::vector<std::pair<size_t, int>> spans;  // (first event index, 0 = extend / 1 = shade / 2 = tail launch next to k_extend)
@@ -804,7 +807,7 @@ struct Engine : EngineBase {
                 if (timing) HIP_CHECK(hipEventRecord(event(ev + 2), stream));
                 ev += 3;
                 deepest = std::max(deepest, depth + 1);
-                if ((depth & 3) == 3 && depth + 1 < max_bounces) {
+                if ((depth + 1) % peek_every == 0 && depth + 1 < max_bounces) {
                     // Every 4th bounce: is anything still alive?  (One 4-byte read-back.)
                     HIP_CHECK(hipMemcpyAsync(host_counts, counts.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                     HIP_CHECK(hipStreamSynchronize(stream));
