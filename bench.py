@@ -128,6 +128,9 @@ def main() -> None:
                     help="strong scaling: --spp is the whole image's sample count, split over the GPUs (default: weak, --spp per GPU)")
     args = ap.parse_args()
 
+    if args.overlap > 1:  # two streams share the CUs: 8 persistent blocks per CU each measure best
+        os.environ.setdefault("RT_GRID_MULT", "8")
+
     import torch
 
     import raytracer_amd as rt

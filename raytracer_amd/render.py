@@ -255,6 +255,9 @@ def main(argv=None) -> int:
                     help="concurrent batches per GPU (2: about 12 %% faster; the picture may differ from --overlap 1 in the last bit of a sum)")
     args = ap.parse_args(argv)
 
+    if args.overlap > 1:  # two streams share the CUs: 8 persistent blocks per CU each measure best
+        os.environ.setdefault("RT_GRID_MULT", "8")
+
     import torch
 
     import raytracer_amd as rt
