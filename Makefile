@@ -23,15 +23,17 @@ $(OBJDIR)/%.o: $(HOSTDIR)/%.cpp $(HOST_HDRS)
 	@mkdir -p $(OBJDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(OBJDIR)/kernels.o: raytracer_amd/csrc/device/kernels.hip raytracer_amd/csrc/device/rt_device.h include/rt_mi355x.h
+# kernels.hip is compiled once per group of instantiations (RT_PART 0-5), in parallel
+KERNEL_OBJS := $(foreach p,0 1 2 3 4 5,$(OBJDIR)/kernels_$(p).o)
+$(OBJDIR)/kernels_%.o: raytracer_amd/csrc/device/kernels.hip raytracer_amd/csrc/device/rt_device.h include/rt_mi355x.h
 	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DRT_PART=$* -c $< -o $@
 
 $(OBJDIR)/capi.o: raytracer_amd/csrc/capi.cpp raytracer_amd/csrc/tree_layout.hpp raytracer_amd/csrc/device/rt_device.h $(HOST_HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/librt_mi355x.so: $(HOST_OBJS) $(OBJDIR)/kernels.o $(OBJDIR)/capi.o
+$(LIBDIR)/librt_mi355x.so: $(HOST_OBJS) $(KERNEL_OBJS) $(OBJDIR)/capi.o
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lz
 

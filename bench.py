@@ -73,26 +73,43 @@ def measured_traffic(scene_name: str, prec: str, kernel: str = None):
     return None
 
 
+def host_threads() -> int:
+    """The host hardware threads this job may use: the affinity mask, capped by the box's own share (the GPU box
+    exports OMP_NUM_THREADS = its CPU share per GPU, 16; os.cpu_count() there shows the whole machine)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS")
+    if share and share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return max(1, n)
+
+
 def cpu_baseline(scene_path: str, width: int, bounces: int, seed: int, asset_root: str = ROOT) -> dict:
-    """CPU oracle on a bounded sample of the workload: same scene / width / bounces, fewer
-    samples per pixel (rays per sample are the same in expectation)."""
+    """CPU oracle on a bounded sample of the workload: same scene / width / bounces, fewer samples per pixel
+    (rays per sample are the same in expectation); every host thread we may use, median of 3 runs."""
     from oracle import binding as orc
 
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads = host_threads()
     sc = orc.OracleScene.load(scene_path, asset_root)
     H = sc.image_height(width)
-    spp = 1
     t0 = time.time()
-    _, _, rays = sc.render(width, H, 0, H, spp, bounces, seed, threads=threads)
+    sc.render(width, H, 0, H, 1, bounces, seed, threads=threads)
     dt = time.time() - t0
-    # Scale the sample so that it is about 20 s of CPU work (thread-seconds), at most 16 spp.
-    spp2 = int(max(1, min(16, round(20.0 / max(dt * threads, 1e-3)))))
-    t0 = time.time()
-    _, _, rays = sc.render(width, H, 0, H, spp2, bounces, seed, threads=threads)
-    dt = time.time() - t0
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    # Each of the 3 runs is about 7 s of wall time (20 s of CPU work in all), at most 16 spp.
+    spp2 = int(max(1, min(16, round(7.0 / max(dt, 1e-3)))))
+    runs = []
+    for k in range(3):
+        t0 = time.time()
+        _, _, rays = sc.render(width, H, 0, H, spp2, bounces, seed + k, threads=threads)
+        runs.append((rays / (time.time() - t0) / 1e6, rays, time.time() - t0))
+    runs.sort()
+    value, rays, dt = runs[1]
+    return {"value": value, "unit": "Mrays/s", "cores": threads, "kind": "port", "runs_Mrays_s": [round(r[0], 2) for r in runs],
             "sample": f"{os.path.basename(scene_path)} {width}x{H}, {spp2} spp of the workload's samples, {bounces} bounces, "
-                      f"{rays} rays in {dt:.2f} s; C++ f64 restatement of the reference renderer (oracle/), {threads} threads"}
+                      f"median of 3 runs ({rays} rays in {dt:.2f} s); C++ f64 restatement of the reference renderer (oracle/, "
+                      f"g++ -O3 -march=x86-64-v3: built before it travels to the box, so not -march=native), {threads} threads = every host thread of the box's share"}
 
 
 class MergedStats:
@@ -106,54 +123,26 @@ class MergedStats:
         self.extend_kernel = parts[-1].extend_kernel
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="cornell")
-    ap.add_argument("--width", type=int, default=600)
-    ap.add_argument("--spp", type=int, default=100, help="samples per pixel per GPU")
-    ap.add_argument("--bounces", type=int, default=50)
-    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--triangles", type=int, default=0,
-                    help="--scene knight only: generate the stand-in mesh with about this many triangles in a scratch "
-                         "directory (default: the ~100 k-triangle examples/knight.obj; BASELINE configs[4] names ~1 M)")
-    ap.add_argument("--overlap", type=int, default=1,
-                    help="render a rank's samples as this many concurrent batches (one context = one stream and one host thread each) "
-                         "so that one batch's latency-bound late bounces run under another's early ones (DESIGN.md section 7; default 1: off)")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: --spp is the whole image's sample count, split over the GPUs (default: weak, --spp per GPU)")
-    args = ap.parse_args()
+def measured_valu(scene_name: str, prec: str, kernel: str):
+    """VALU wave-instructions per ray of the dominant kernel from the SQ_INSTS_VALU pass committed under profiles/
+    (rocprofv3 --pmc, its own run); None when no pass exists for this scene / kernel."""
+    import glob
 
-    if args.overlap > 1:  # two streams share the CUs: 8 persistent blocks per CU each measure best (DESIGN.md section 7)
-        os.environ.setdefault("RT_GRID_MULT", "8")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "valu.json")), reverse=True):
+        with open(path) as f:
+            t = json.load(f).get(scene_name)
+        if t and t.get("precision") == prec and t.get("kernel") == kernel:
+            return t
+    return None
 
-    import torch
 
-    import raytracer_amd as rt
-    from raytracer_amd import parallel
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4 / 1e9   # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
 
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
-
-    scene_path = os.path.join(ROOT, "examples", args.scene + ".json5")
+def load_scene(rt, args, scene_name):
+    scene_path = os.path.join(ROOT, "examples", scene_name + ".json5")
     asset_root = ROOT
-    if args.scene == "knight":
+    if scene_name == "knight":
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import gen_knight
 
@@ -168,7 +157,14 @@ def main() -> None:
             scene_path = os.path.join(asset_root, "examples", "knight.json5")
         else:
             gen_knight.ensure(os.path.join(ROOT, "examples", "knight.obj"))
+    t0 = time.perf_counter()
     scene = rt.Scene.load(scene_path, asset_root)
+    return scene, scene_path, asset_root, (time.perf_counter() - t0) * 1e3
+
+
+def run_workload(args, scene_name, steps, warmup, torch, rt, parallel, dist, rank, local_rank, world, with_cpu):
+    """Times `steps` whole images of one scene; returns the JSON line (rank 0) or None."""
+    scene, scene_path, asset_root, ms_load = load_scene(rt, args, scene_name)
     W = args.width
     H = scene.image_height(W)
     npix = W * H
@@ -176,16 +172,18 @@ def main() -> None:
     renderers = []
     for _ in range(K):
         r = rt.Renderer(device=local_rank, precision=rt.PRECISION_F64 if args.precision == "f64" else rt.PRECISION_F32,
-                        max_paths=(1 << 26) // K)
+                        max_paths=(1 << 26) // K, lanes=args.lanes)
         r.upload(scene)
         renderers.append(r)
     renderer = renderers[0]
+    up = renderer.upload_stats()
 
     dev = torch.device("cuda", local_rank)
     accum = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
     extra_accum = [torch.zeros(npix * 3, dtype=torch.float64, device=dev) for _ in range(K - 1)]
     rgb8 = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
-    total_spp = args.spp if args.strong else args.spp * world
+    strong = args.strong
+    total_spp = args.spp if strong else args.spp * world
     s0, ns = parallel.split_samples(total_spp, world, rank)
 
     def barrier():
@@ -210,19 +208,26 @@ def main() -> None:
 
     if dist is not None:  # RCCL sets its connections up in the first collective of each kind: not a step, never timed
         parallel.reduce_to_root(torch.zeros(1024, dtype=torch.float64, device=dev), dist)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(None)
     stats = []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(steps):
+        # HIP events around every launch cost the stream ~5 us each, so only the LAST timed
+        # step carries them: its launch durations feed `roofline`, all steps feed `value`.
+        if k == steps - 1:
+            for r in renderers:
+                r.set_launch_timing(True)
         step(stats)
     barrier()
     dt = time.perf_counter() - t0
+    for r in renderers:
+        r.set_launch_timing(False)
 
     rays = sum(s.rays for s in stats)
-    t = torch.tensor([dt, float(rays), sum(s.ms_extend for s in stats), float(sum(s.extend_launches for s in stats)),
-                      sum(s.ms_shade for s in stats), sum(s.ms_total for s in stats)], dtype=torch.float64, device=dev)
+    last = stats[-1]
+    t = torch.tensor([dt, float(rays), sum(s.ms_total for s in stats)], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -233,11 +238,10 @@ def main() -> None:
     else:
         rays_all = float(rays)
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
 
-    ms_extend, n_extend = float(t[2]), float(t[3])
+    # ---- the dominant kernel, from the launches of the last timed step (HIP events on the library's own streams)
+    ms_extend, n_extend = float(last.ms_extend), float(last.extend_launches)
     r = REC[args.precision]
     counts = scene.counts()
     # Records k_extend can touch (everything but materials / texels), as laid out in HBM.
@@ -249,66 +253,151 @@ def main() -> None:
     # The records a traversal touches again and again (SURVEY.md 8d's per-ray sum) are served by
     # LDS / L2 / Infinity Cache and are reported separately as `touched`.
     # (the tail launch of a two-kernel render is another kernel: its rays and time are reported apart)
-    rays_tail = float(sum(s.rays_tail for s in stats))
-    ms_tail = float(sum(s.ms_tail for s in stats))
-    rays_per_launch = (rays - rays_tail) / max(n_extend, 1.0)
+    rays_step = float(last.rays)
+    rays_tail = float(last.rays_tail)
+    ms_tail = float(last.ms_tail)
+    fused = last.extend_kernel == 2
+    kernel = "k_bounce" if fused else "k_extend_refill" if last.extend_kernel == 1 else "k_extend"
+    if fused and last.tail_launches == 0 and n_extend > 0:
+        pass
+    rays_per_launch = (rays_step - rays_tail) / max(n_extend, 1.0)
     ms_per_launch = ms_extend / max(n_extend, 1.0)
     # Small worlds of rects and spheres run extend + shade as ONE kernel per bounce (k_bounce; the
     # library reports its time as ms_extend and no shade launches): it reads a path's queue entry
     # (ray 56 B + throughput 24 B + path id 4 B in f64) and writes one for every survivor; the
     # survivors of all launches are the rays of the later launches = rays - paths.
-    fused = sum(s.shade_launches for s in stats) == 0 and n_extend > 0
-    kernel = "k_bounce" if fused else "k_extend_refill" if stats and stats[-1].extend_kernel == 1 else "k_extend"
     path_bytes = 84 if args.precision == "f64" else 44
-    paths = float(sum(s.paths for s in stats))
+    paths = float(last.paths)
     if fused:
-        bytes_per_launch = (path_bytes * rays + path_bytes * (rays - paths)) / max(n_extend, 1.0) + scene_bytes
-        bytes_per_ray = path_bytes * (2.0 - paths / max(rays, 1.0))
+        bytes_per_launch = (path_bytes * rays_step + path_bytes * (rays_step - paths)) / max(n_extend, 1.0) + scene_bytes
+        bytes_per_ray = path_bytes * (2.0 - paths / max(rays_step, 1.0))
     else:
         bytes_per_launch = (r["ray"] + r["hit"]) * rays_per_launch + scene_bytes
         bytes_per_ray = r["ray"] + r["hit"]
     achieved_gbs = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
-    touched_bpr = extend_bytes_per_ray(args.scene, args.precision)
-    touched_gbs = touched_bpr * (rays - rays_tail) / (ms_extend * 1e-3) / 1e9 if ms_extend > 0 else 0.0
-    flops = extend_flops_per_ray(args.scene) * (rays - rays_tail) / (ms_extend * 1e-3) / 1e12 if ms_extend > 0 else 0.0
+    touched_bpr = extend_bytes_per_ray(scene_name, args.precision)
+    touched_gbs = touched_bpr * (rays_step - rays_tail) / (ms_extend * 1e-3) / 1e9 if ms_extend > 0 else 0.0
+    flops = extend_flops_per_ray(scene_name) * (rays_step - rays_tail) / (ms_extend * 1e-3) / 1e12 if ms_extend > 0 else 0.0
     valu_peak = FP64_VALU_PEAK_TFLOPS if args.precision == "f64" else FP32_VALU_PEAK_TFLOPS
+    default_mesh = args.triangles == 0
+    valu = measured_valu(scene_name, args.precision, kernel) if default_mesh else None
+    hbm = {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+           "bytes_per_launch": bytes_per_launch, "bytes_per_ray": bytes_per_ray, "scene_bytes": scene_bytes,
+           "traffic": measured_traffic(scene_name, args.precision, kernel) if default_mesh else None,  # PMC passes exist for the default meshes only
+           "touched": {"bytes_per_ray": touched_bpr, "achieved_GBps": touched_gbs,
+                       "note": "all records the reference traversal touches per ray (SURVEY 8d sum, f64 sizes); served by SGPR loads / LDS / L2 / "
+                               "Infinity Cache, NOT HBM bytes (BASELINE.md)"}}
+    if valu is not None:
+        # What binds: VALU issue.  wave-instructions per ray (SQ_INSTS_VALU of the kernel / its rays, a property of
+        # kernel + scene, from the committed PMC pass) x the rays of a launch / the launch's duration measured here.
+        issue = valu["valu_insts_per_ray"] * rays_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        roofline = {"bound": "valu_issue", "kernel": kernel, "achieved": issue, "peak": VALU_ISSUE_PEAK, "unit": "Gwaveinstr/s",
+                    "frac": issue / VALU_ISSUE_PEAK, "traffic": hbm["traffic"],
+                    "valu_insts_per_ray": valu["valu_insts_per_ray"], "valu_source": valu.get("source"),
+                    "note": kernel + " is bound by VALU issue (f64: one wave64 instruction per 4 cycles per SIMD; divisions and square roots are "
+                            "instruction sequences) and, on meshes, by dependent-fetch latency - not by HBM bandwidth, whose fraction is under `hbm`"}
+    else:
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": hbm["traffic"],
+                    "note": "no SQ_INSTS_VALU pass is committed for this scene / kernel: priced against HBM only"}
+    roofline.update({"hbm": hbm, "launches": n_extend, "avg_launch_ms": ms_per_launch, "rays_per_launch": rays_per_launch,
+                     "launch_timing": "HIP events on the library's streams around every launch of the last timed step"})
     out = {
         "metric": "Mrays/sec (whole node)",
         "value": rays_all / dt / 1e6,
         "unit": "Mrays/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong" if args.strong else "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": args.precision,
-        "data": "synthetic" if args.scene == "knight" else "reference example scene",
+        "data": "synthetic" if scene_name == "knight" else "reference example scene",
         "config": {
-            "workload": f"examples/{args.scene}.json5 {W}x{H}, {total_spp // world if args.strong else args.spp} spp per GPU ({total_spp} spp image), "
-                        f"{args.bounces} bounces, sample-split across {world} GPU(s), reduce to rank 0, quantise",
-            "triangles": scene.counts()["triangles"], "paths_per_step": npix * total_spp, "rays_per_step": rays_all / args.steps,
-            "wall_clock_per_image_s": dt / args.steps, "seed": args.seed, "concurrent_batches_per_gpu": K,
+            "workload": f"examples/{scene_name}.json5 {W}x{H}, {ns} spp on this GPU ({total_spp} spp image, "
+                        f"{'strong' if strong else 'weak'} scaling), {args.bounces} bounces, sample-split across {world} GPU(s), reduce to rank 0, quantise",
+            "spp_per_gpu": ns, "spp_image": total_spp,
+            "triangles": counts["triangles"], "paths_per_step": npix * total_spp, "rays_per_step": rays_all / steps,
+            "wall_clock_per_image_s": dt / steps, "seed": args.seed, "concurrent_batches_per_gpu": K, "lanes": args.lanes,
         },
-        "roofline": {
-            "bound": "hbm", "kernel": kernel, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS,
-            "traffic": None if args.triangles > 0 else measured_traffic(args.scene, args.precision, kernel),  # PMC passes exist for the default meshes only
-            "bytes_per_launch": bytes_per_launch, "bytes_per_ray": bytes_per_ray, "scene_bytes": scene_bytes,
-            "launches": n_extend, "avg_launch_ms": ms_per_launch, "rays_per_launch": rays_per_launch,
-            "touched": {"bytes_per_ray": touched_bpr, "achieved_GBps": touched_gbs,
-                        "note": "all records the reference traversal touches per ray (SURVEY 8d sum, f64 sizes); served mostly by LDS / L2 / Infinity Cache"},
-            "note": kernel + " is bound by f64 VALU issue (and, on meshes, dependent-fetch latency), not by HBM bandwidth "
-                    "(see roofline_valu, profiles/ and DESIGN.md)",
-        },
-        "roofline_valu": {"kernel": kernel, "achieved": flops, "peak": valu_peak, "unit": "TFLOP/s", "frac": flops / valu_peak},
-        "stage_ms_per_step": {"extend": ms_extend / args.steps, "shade": float(t[4]) / args.steps, "tail": ms_tail / args.steps,
-                              "gpu_total": float(t[5]) / args.steps},
+        "roofline": roofline,
+        "roofline_valu": {"kernel": kernel, "achieved": flops, "peak": valu_peak, "unit": "TFLOP/s", "frac": flops / valu_peak,
+                          "note": "SURVEY 8d's nominal flops (21 per box, 17 rect, 25 sphere, 52 triangle): counts neither divisions as sequences nor addressing"},
+        "stage_ms_last_step": {"extend": ms_extend, "shade": float(last.ms_shade), "tail": ms_tail, "gpu_total": float(last.ms_total),
+                               "extend_launches": int(last.extend_launches), "shade_launches": int(last.shade_launches),
+                               "tail_launches": int(last.tail_launches)},
+        "scene_setup_ms": {"load_and_flatten": ms_load, "upload_total": up.ms_total, "upload_validate": up.ms_validate,
+                           "upload_build_layouts": up.ms_build, "upload_copy": up.ms_copy, "device_bytes": int(up.bytes_device),
+                           "note": "outside the timed region, as the reference's own timer starts after load_config (src/main.rs:84)"},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and with_cpu:
         out["cpu_baseline"] = cpu_baseline(scene_path, W, args.bounces, args.seed, asset_root)
-    print(json.dumps(out), flush=True)
+    for rr in renderers:
+        rr.close()
+    return out
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--width", type=int, default=600)
+    ap.add_argument("--spp", type=int, default=100, help="samples per pixel of the image (strong scaling) / per GPU (--weak)")
+    ap.add_argument("--bounces", type=int, default=50)
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1, default scene only: skip the second workload (knight) of the `workloads` array")
+    ap.add_argument("--triangles", type=int, default=0,
+                    help="--scene knight only: generate the stand-in mesh with about this many triangles in a scratch "
+                         "directory (default: the ~100 k-triangle examples/knight.obj; BASELINE configs[4] names ~1 M)")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="(round-1 experiment) render a rank's samples as this many concurrent contexts, one host thread each; "
+                         "the library's own lanes (--lanes) replace it")
+    ap.add_argument("--lanes", type=int, default=0, help="rt_options.lanes: streams that share a call's sample batches (0: the library's default)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --spp is the whole image's sample count, split over the GPUs (the default for N > 1)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --spp samples per GPU, an N x spp image")
+    args = ap.parse_args()
+    args.strong = args.strong or (args.gpus > 1 and not args.weak) or int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.weak
+
+    if args.overlap > 1:  # two streams share the CUs: 8 persistent blocks per CU each measure best (DESIGN.md section 7)
+        os.environ.setdefault("RT_GRID_MULT", "8")
+
+    import torch
+
+    import raytracer_amd as rt
+    from raytracer_amd import parallel
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    out = run_workload(args, args.scene, args.steps, args.warmup, torch, rt, parallel, dist, rank, local_rank, world,
+                       with_cpu=not args.no_cpu_baseline)
+    # BASELINE.json's metric names cornell AND knight: the default one-GPU run carries the knight line too.
+    if world == 1 and args.scene == "cornell" and not args.no_extra and args.triangles == 0 and args.spp == 100:
+        extra = run_workload(args, "knight", max(2, min(args.steps, 3)), 1, torch, rt, parallel, dist, rank, local_rank, world,
+                             with_cpu=not args.no_cpu_baseline)
+        keys = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "data", "config", "roofline", "stage_ms_last_step",
+                "scene_setup_ms", "cpu_baseline")
+        out["workloads"] = [{k: out[k] for k in keys if k in out}, {k: extra[k] for k in keys if k in extra}]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -177,8 +177,10 @@ enum { RT_PRECISION_F64 = 0, RT_PRECISION_F32 = 1 };
 
 typedef struct rt_options {
     int32_t precision;     /* RT_PRECISION_F64 (reference arithmetic, default) or _F32 */
-    int32_t reserved;
-    uint64_t max_paths;    /* paths in flight per batch; 0 = default (2^25) */
+    int32_t lanes;         /* streams (each with its own ray queues) that share the sample batches of a render call, so
+                            * that the latency-bound end of one batch runs under the bulk of the next; 0 = default.  The
+                            * image does not depend on it bit for bit (sums are added in sample order). */
+    uint64_t max_paths;    /* paths in flight per context, shared by the lanes; 0 = default (2^25) */
 } rt_options;
 
 int rt_create(int device_id, const rt_options* options /* may be NULL */, rt_context** out);
@@ -188,6 +190,19 @@ const char* rt_last_error(const rt_context* ctx);
 /* Copies the scene to the context's GPU (the scene is replicated per GPU).  The host
  * arrays may be freed after the call returns. */
 int rt_upload_scene(rt_context* ctx, const rt_scene_desc* scene);
+
+/* What the last rt_upload_scene cost ("scene upload / BVH build reported separately"; the
+ * reference builds its tree inside load_config, src/config.rs:36 -> src/hitting.rs:147-197, outside its own
+ * render timer, src/main.rs:84).  No counterpart in the reference: measurement. */
+typedef struct rt_upload_stats {
+    double ms_validate;    /* host: every index of the description checked */
+    double ms_build;       /* host: traversal layouts derived from `nodes` (two-box nodes, SAH-regrouped four-wide trees, 8-bit quantisation) + their copies */
+    double ms_copy;        /* host: record conversion + host-to-device copies of everything else */
+    double ms_total;
+    uint64_t bytes_device; /* scene bytes resident on the GPU */
+    uint32_t n_nodes2, n_nodes4, sah_trees, pad;
+} rt_upload_stats;
+int rt_get_upload_stats(rt_context* ctx, rt_upload_stats* out);
 
 /* Parity entry point.  Replaces `world.hit(ray, tmin, tmax)` (trait Hittable,
  * src/hitting.rs:82-86, as called at src/hitting.rs:21) on explicit rays.  Directions are
@@ -227,6 +242,10 @@ typedef struct rt_stats {
     uint32_t tail_launches;
     uint32_t extend_kernel; /* which kernel ms_extend times: 0 k_extend, 1 k_extend_refill, 2 k_bounce (fused) */
 } rt_stats;
+/* ms_extend / ms_shade / ms_tail are filled only while launch timing is on: a HIP event either side of every launch
+ * costs the stream about 5 us each (0.7 ms of a 21 ms image), so it is off by default; rays, paths, launch counts
+ * and ms_total are always filled.  No counterpart in the reference: measurement. */
+int rt_set_launch_timing(rt_context* ctx, int on);
 
 /* Replaces the row closure of src/main.rs:124-137 (+ cast_ray, src/hitting.rs:11-31) for
  * rows [j0, j1) and sample indices [s0, s0 + n_samples) of every pixel: ADDS the radiance

@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 __all__ = [
-    "load_library", "Scene", "Renderer", "RtError", "RtStats", "RAY_DTYPE", "HIT_DTYPE",
+    "load_library", "Scene", "Renderer", "RtError", "RtStats", "RtUploadStats", "RAY_DTYPE", "HIT_DTYPE",
     "PRECISION_F64", "PRECISION_F32", "LIB_PATH", "PartFile", "read_part_file", "save_image", "ProgressBar",
 ]
 
@@ -44,7 +44,7 @@ class RtError(RuntimeError):
 
 
 class RtOptions(C.Structure):
-    _fields_ = [("precision", C.c_int32), ("reserved", C.c_int32), ("max_paths", C.c_uint64)]
+    _fields_ = [("precision", C.c_int32), ("lanes", C.c_int32), ("max_paths", C.c_uint64)]
 
 
 class RtStats(C.Structure):
@@ -57,6 +57,17 @@ class RtStats(C.Structure):
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class RtUploadStats(C.Structure):
+    _fields_ = [
+        ("ms_validate", C.c_double), ("ms_build", C.c_double), ("ms_copy", C.c_double), ("ms_total", C.c_double),
+        ("bytes_device", C.c_uint64), ("n_nodes2", C.c_uint32), ("n_nodes4", C.c_uint32), ("sah_trees", C.c_uint32),
+        ("pad", C.c_uint32),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "pad"}
 
 
 # Every symbol include/rt_mi355x.h declares: (name, restype, argtypes).
@@ -72,6 +83,8 @@ EXPORTS = [
     ("rt_destroy", None, [_vp]),
     ("rt_last_error", C.c_char_p, [_vp]),
     ("rt_upload_scene", C.c_int, [_vp, _vp]),
+    ("rt_get_upload_stats", C.c_int, [_vp, C.POINTER(RtUploadStats)]),
+    ("rt_set_launch_timing", C.c_int, [_vp, C.c_int]),
     ("rt_trace", C.c_int, [_vp, _vp, C.c_size_t, _u64, _vp]),
     ("rt_primary_rays", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u64, _vp]),
     ("rt_render_accum_device", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _vp, C.POINTER(RtStats)]),
@@ -187,9 +200,9 @@ class Scene:
 class Renderer:
     """One GPU's render context (rt_context)."""
 
-    def __init__(self, device: int = 0, precision: int = PRECISION_F64, max_paths: int = 0):
+    def __init__(self, device: int = 0, precision: int = PRECISION_F64, max_paths: int = 0, lanes: int = 0):
         lib = load_library()
-        opts = RtOptions(precision, 0, max_paths)
+        opts = RtOptions(precision, lanes, max_paths)
         out = _vp()
         rc = lib.rt_create(device, C.byref(opts), C.byref(out))
         if rc != 0:
@@ -204,6 +217,15 @@ class Renderer:
 
     def upload(self, scene: Scene) -> None:
         self._check(self._lib.rt_upload_scene(self._h, scene.desc_ptr))
+
+    def upload_stats(self) -> RtUploadStats:
+        out = RtUploadStats()
+        self._check(self._lib.rt_get_upload_stats(self._h, C.byref(out)))
+        return out
+
+    def set_launch_timing(self, on: bool) -> None:
+        """HIP events around every launch (fills RtStats.ms_extend / ms_shade / ms_tail; costs ~5 us per event)."""
+        self._check(self._lib.rt_set_launch_timing(self._h, int(on)))
 
     def trace(self, rays: np.ndarray, seed: int = 0) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)

@@ -6,6 +6,7 @@
 // and fails with RT_ERR_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -198,13 +199,173 @@ void validate(const rt_scene_desc& d) {
 
 template <typename T> void cvt3(T* o, const double* s) { o[0] = (T)s[0]; o[1] = (T)s[1]; o[2] = (T)s[2]; }
 
+// ---- work buffers of one lane.  Raw device pointers: either views of hipMalloc'ed buffers that grow on
+// demand (OwnedWork) or pieces of the library's static device array (carve_work: the allocation-free entry point).
+template <typename T>
+struct Work {
+    T* qslab[2] = {nullptr, nullptr};  // two ray queues, 10 fields of `capacity` entries each
+    uint32_t* qpid[2] = {nullptr, nullptr};
+    T* hslab = nullptr;  // hit records, 6 fields
+    uint32_t* hmat = nullptr;
+    T* sample_rgb = nullptr;  // per-path radiance of a batch
+    uint32_t* tile_counts[2] = {nullptr, nullptr};
+    uint32_t* tile_offsets = nullptr;
+    uint32_t* counts = nullptr;  // [0] live paths after the last scan, [1] k_extend_refill's cursor, [2] deepest bounce reached inside a tail launch, [3] the tail launch's cursor
+    unsigned long long* ray_total = nullptr;  // [0] closest-hit queries counted by the scans, [1] those issued inside a tail launch beyond its first bounce, [2] paths that entered tail launches
+    int32_t* hids = nullptr;  // rt_trace only
+    T* tminmax = nullptr;     // rt_trace only
+    size_t capacity = 0;         // paths the queues hold
+    size_t sample_capacity = 0;  // paths sample_rgb holds
+};
+
+template <typename T>
+struct OwnedWork {
+    DevBuf<T> qslab[2], hslab, sample_rgb, tminmax;
+    DevBuf<uint32_t> qpid[2], hmat;
+    DevBuf<int32_t> hids;
+    DevBuf<uint32_t> counts, tile_counts[2], tile_offsets;
+    DevBuf<unsigned long long> ray_total;
+    void ensure(Work<T>& w, size_t n, size_t n_samples, bool with_ids) {
+        if (!counts.p) {
+            counts.ensure(4);
+            ray_total.ensure(3);
+        }
+        if (n > w.capacity) {
+            for (int k = 0; k < 2; k++) {
+                qslab[k].ensure(n * 10);
+                qpid[k].ensure(n);
+            }
+            hslab.ensure(n * 6);
+            hmat.ensure(n);
+            for (int k = 0; k < 2; k++) tile_counts[k].ensure((n + RT_TILE - 1) / RT_TILE);
+            tile_offsets.ensure((n + RT_TILE - 1) / RT_TILE + 1);
+            w.capacity = n;
+        }
+        if (n_samples > w.sample_capacity) {
+            sample_rgb.ensure(n_samples * 3);
+            w.sample_capacity = n_samples;
+        }
+        if (with_ids) {
+            hids.ensure(w.capacity * 3);
+            tminmax.ensure(w.capacity * 2);
+        }
+        for (int k = 0; k < 2; k++) {
+            w.qslab[k] = qslab[k].p;
+            w.qpid[k] = qpid[k].p;
+            w.tile_counts[k] = tile_counts[k].p;
+        }
+        w.hslab = hslab.p; w.hmat = hmat.p; w.sample_rgb = sample_rgb.p; w.tile_offsets = tile_offsets.p;
+        w.counts = counts.p; w.ray_total = ray_total.p; w.hids = hids.p; w.tminmax = tminmax.p;
+    }
+};
+
+// Paths in flight of the allocation-free entry point, and the bytes of its buffers (f64: 244 B per path).
+#define RT_NOALLOC_MAX_PATHS (1u << 17)
+#define RT_DEFAULT_LANES 2
+constexpr size_t work_bytes(size_t elem, size_t paths) {
+    const size_t tiles = (paths + RT_TILE - 1) / RT_TILE;
+    return 2 * (paths * 10 * elem + paths * 4) + paths * 6 * elem + paths * 4 + paths * 3 * elem  // queues, hits, samples
+           + (3 * tiles + 1) * 4 + 4 * 4 + 3 * 8                                                  // tile counts / offsets, counters
+           + 16 * 256;                                                                            // every piece starts on a 256-byte boundary
+}
+template <typename T>
+Work<T> carve_work(unsigned char* base, size_t bytes, size_t paths) {
+    Work<T> w;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        unsigned char* p = base + off;
+        off += (n + 255) & ~(size_t)255;
+        return p;
+    };
+    const size_t tiles = (paths + RT_TILE - 1) / RT_TILE;
+    for (int k = 0; k < 2; k++) {
+        w.qslab[k] = (T*)take(paths * 10 * sizeof(T));
+        w.qpid[k] = (uint32_t*)take(paths * 4);
+        w.tile_counts[k] = (uint32_t*)take(tiles * 4);
+    }
+    w.hslab = (T*)take(paths * 6 * sizeof(T));
+    w.hmat = (uint32_t*)take(paths * 4);
+    w.sample_rgb = (T*)take(paths * 3 * sizeof(T));
+    w.tile_offsets = (uint32_t*)take((tiles + 1) * 4);
+    w.counts = (uint32_t*)take(4 * 4);
+    w.ray_total = (unsigned long long*)take(3 * 8);
+    if (off > bytes) throw RtError{RT_ERR_INVALID, "internal: the static work area is too small"};
+    w.capacity = paths;
+    w.sample_capacity = paths;
+    return w;
+}
+
+// One lane: a stream, its work buffers and the pinned words through which the kernels tell the host how
+// many paths are alive (k_scan_tiles stores the count of every bounce there; the host never waits for the
+// stream to learn it).
+constexpr uint32_t PEEK_SLOTS = 256;  // ring of per-bounce live counts, indexed by depth % PEEK_SLOTS
+constexpr uint32_t PEEK_UNKNOWN = 0xffffffffu;
+template <typename T>
+struct Lane {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool fixed = false;  // buffers are pieces of the static device array: never grown
+    Work<T> w;
+    OwnedWork<T> owned;
+    uint32_t* peek = nullptr;              // pinned, device-visible: PEEK_SLOTS live counts
+    unsigned long long* readback = nullptr;  // pinned: ray totals [0..2], deepest [3]
+    hipEvent_t ev_acc = nullptr;   // recorded after a batch's k_accumulate (the next batch's accumulate waits for it)
+    hipEvent_t ev_join = nullptr;  // recorded when the lane has enqueued all its work of a call
+    std::vector<hipEvent_t> events;  // launch timing
+    explicit Lane(hipStream_t st) {
+        if (st) stream = st;
+        else {
+            HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            own_stream = true;
+        }
+        HIP_CHECK(hipHostMalloc((void**)&peek, PEEK_SLOTS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_CHECK(hipHostMalloc((void**)&readback, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_acc, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    Lane(const Lane&) = delete;
+    Lane& operator=(const Lane&) = delete;
+    ~Lane() {
+        if (peek) (void)hipHostFree(peek);
+        if (readback) (void)hipHostFree(readback);
+        if (ev_acc) (void)hipEventDestroy(ev_acc);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        for (auto e : events) (void)hipEventDestroy(e);
+        if (own_stream) (void)hipStreamDestroy(stream);
+    }
+    void ensure(size_t n, size_t n_samples, bool with_ids) {
+        if (fixed) {
+            if (n > w.capacity || n_samples > w.sample_capacity || with_ids)
+                throw RtError{RT_ERR_INVALID, "internal: request beyond the static work area"};
+            return;
+        }
+        owned.ensure(w, n, n_samples, with_ids);
+    }
+    uint32_t* peek_dev() const {  // the pinned words as the kernels address them
+        void* d = nullptr;
+        HIP_CHECK(hipHostGetDevicePointer(&d, peek, 0));
+        return (uint32_t*)d;
+    }
+    uint32_t peek_value(uint32_t depth) const { return __atomic_load_n(&peek[depth % PEEK_SLOTS], __ATOMIC_ACQUIRE); }
+    hipEvent_t event(size_t k) {
+        while (events.size() <= k) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreate(&e));
+            events.push_back(e);
+        }
+        return events[k];
+    }
+};
+
 struct EngineBase {
     virtual ~EngineBase() {}
     virtual void upload(const rt_scene_desc& d) = 0;
     virtual void trace(const rt_ray* rays, size_t n, uint64_t seed, rt_hit* out) = 0;
     virtual void primary_rays(uint32_t W, uint32_t H, uint32_t j0, uint32_t j1, uint32_t sample, uint64_t seed, rt_ray* out) = 0;
     virtual void render_accum(uint32_t W, uint32_t H, uint32_t j0, uint32_t j1, uint32_t s0, uint32_t ns,
-                              uint32_t max_bounces, uint64_t seed, double* accum_dev, rt_stats* stats) = 0;
+                              uint32_t max_bounces, uint64_t seed, double* accum_dev, rt_stats* stats, bool fixed) = 0;
+    virtual void set_launch_timing(bool on) = 0;
+    virtual void upload_stats(rt_upload_stats* out) = 0;
 };
 
 template <typename T>
@@ -236,31 +397,39 @@ struct Engine : EngineBase {
     DevBuf<int32_t> top_list, sweep;
     DevBuf<unsigned char> small_blob;
     rtd::DSmallScene small;
-    // work buffers
-    DevBuf<T> qslab[2], hslab, sample_rgb, tminmax;
-    DevBuf<uint32_t> qpid[2], hmat;
-    DevBuf<int32_t> hids;
-    DevBuf<uint32_t> counts, tile_counts[2], tile_offsets;
-    DevBuf<unsigned long long> ray_total;
+    // work buffers: one lane = one stream + one set of queues (render_accum deals its batches over the lanes)
+    std::vector<std::unique_ptr<Lane<T>>> lanes;
+    std::unique_ptr<Lane<T>> fixed_lane;  // the lane of rt_render_accum_device_noalloc: buffers in the library's static device array
     DevBuf<double> io_f64;
     DevBuf<rt_hit> io_hits;
-    size_t capacity = 0;
-    uint32_t* host_counts = nullptr;  // pinned
-    std::vector<hipEvent_t> events;
+    bool time_launches = false;  // rt_set_launch_timing: HIP events around every launch (each costs the stream ~5 us)
+    uint32_t tail_threshold_fused = 1048576u, tail_threshold_tree = 1048576u;  // live paths at or below which the tail launch takes over
+    int tail_blocks_per_cu = 2;  // blocks of the tail launch that stay resident per CU (k_bounce<.., CAN_TAIL = true>: RT_TAIL_WAVES waves per SIMD)
+    rt_upload_stats up_stats;
+    void set_launch_timing(bool on) override { time_launches = on; }
+    void upload_stats(rt_upload_stats* out) override { *out = up_stats; }
 
-    Engine(hipStream_t st, int cus, uint64_t maxp) : stream(st), num_cus(cus), max_paths(maxp) {
+    Engine(hipStream_t st, int cus, uint64_t maxp, int n_lanes, void* fixed_base, size_t fixed_bytes)
+        : stream(st), num_cus(cus), max_paths(maxp) {
         std::memset(&S, 0, sizeof(S));
-        HIP_CHECK(hipHostMalloc((void**)&host_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
-        counts.ensure(4);  // [0] live paths after the last scan, [1] spare, [2] deepest bounce reached inside a tail launch
-        ray_total.ensure(2);  // [0] closest-hit queries, [1] those issued inside a tail launch beyond its first bounce
+        std::memset(&up_stats, 0, sizeof(up_stats));
+        for (int k = 0; k < n_lanes; k++) lanes.emplace_back(new Lane<T>(k == 0 ? st : nullptr));
+        if (fixed_base) {
+            fixed_lane.reset(new Lane<T>(st));
+            fixed_lane->w = carve_work<T>((unsigned char*)fixed_base, fixed_bytes, RT_NOALLOC_MAX_PATHS);
+            fixed_lane->fixed = true;
+        }
     }
-    ~Engine() override {
-        if (host_counts) (void)hipHostFree(host_counts);
-        for (auto e : events) (void)hipEventDestroy(e);
-    }
+    ~Engine() override {}
 
     void upload(const rt_scene_desc& d) override {
+        using clock = std::chrono::steady_clock;
+        auto ms_since = [](clock::time_point t0) { return std::chrono::duration<double, std::milli>(clock::now() - t0).count(); };
+        const clock::time_point t_begin = clock::now();
+        std::memset(&up_stats, 0, sizeof(up_stats));
         validate(d);
+        up_stats.ms_validate = ms_since(t_begin);
+        const clock::time_point t_build = clock::now();
         have_scene = false;
         // Traversal layout: the reference-style tree (rt_node: every node holds its own f64 box) is
         // re-laid as DNode2 records that hold the boxes of both children (see rt_device.h).
@@ -335,6 +504,8 @@ struct Engine : EngineBase {
                 }
             }
         }
+        up_stats.ms_build = ms_since(t_build);  // (includes the copies of the two node arrays)
+        const clock::time_point t_copy = clock::now();
         {
             std::vector<rtd::DObject> v(d.n_objects);
             std::vector<rtd::DBlock<T>> block_corners;
@@ -517,6 +688,17 @@ struct Engine : EngineBase {
             std::fprintf(stderr, "rt_upload_scene: objects %llu, stack_depth %d, four-wide %s (stack need %d, lds cap %d), sweep %d%s\n",
                          (unsigned long long)d.n_objects, stack_depth, S.nodes4 ? (sah_trees ? "sah" : "folded") : "no", stack_need4,
                          S.stack_cap, S.n_sweep, S.lean ? " lean" : "");
+        HIP_CHECK(hipDeviceSynchronize());
+        up_stats.ms_copy = ms_since(t_copy);
+        up_stats.ms_total = ms_since(t_begin);
+        up_stats.n_nodes2 = (uint32_t)n_nodes2;
+        up_stats.n_nodes4 = (uint32_t)(S.nodes4 ? nodes4.n : 0);
+        up_stats.sah_trees = sah_trees ? 1u : 0u;
+        up_stats.bytes_device = nodes2.n * sizeof(rtd::DNode2) + (S.nodes4 ? nodes4.n * sizeof(rtd::DNode4) : 0) + objects.n * sizeof(rtd::DObject) +
+                                blocks.n * sizeof(rtd::DBlock<T>) + xforms.n * sizeof(rtd::DXform<T>) + spheres.n * sizeof(rtd::DSphere<T>) +
+                                moving_spheres.n * sizeof(rtd::DMovingSphere<T>) + rects.n * sizeof(rtd::DRect<T>) +
+                                triangles.n * sizeof(rtd::DTriangle<T>) + planes.n * sizeof(rtd::DPlane<T>) + media.n * sizeof(rtd::DMedium<T>) +
+                                materials.n * sizeof(rtd::DMaterial<T>) + images.n * sizeof(rtd::DImage) + texels.n + top_list.n * 4;
         have_scene = true;
     }
 
@@ -607,43 +789,26 @@ struct Engine : EngineBase {
         std::memcpy(small.off, off, sizeof(off));
     }
 
-    void ensure_capacity(size_t n, bool with_ids) {
-        if (n > capacity) {
-            for (int k = 0; k < 2; k++) {
-                qslab[k].ensure(n * 10);
-                qpid[k].ensure(n);
-            }
-            hslab.ensure(n * 6);
-            hmat.ensure(n);
-            for (int k = 0; k < 2; k++) tile_counts[k].ensure((n + RT_TILE - 1) / RT_TILE);
-            tile_offsets.ensure((n + RT_TILE - 1) / RT_TILE + 1);
-            capacity = n;
-        }
-        if (with_ids) {
-            hids.ensure(capacity * 3);
-            tminmax.ensure(capacity * 2);
-        }
+    static rtd::DQueue<T> queue(const Work<T>& w, int k) {
+        T* b = w.qslab[k];
+        size_t n = w.capacity;
+        return rtd::DQueue<T>{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, w.qpid[k]};
     }
-    rtd::DQueue<T> queue(int k) {
-        T* b = qslab[k].p;
-        size_t n = capacity;
-        return rtd::DQueue<T>{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, qpid[k].p};
-    }
-    rtd::DHits<T> hits(bool with_ids) {
-        T* b = hslab.p;
-        size_t n = capacity;
-        rtd::DHits<T> h{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, hmat.p, nullptr, nullptr, nullptr};
+    static rtd::DHits<T> hits(const Work<T>& w, bool with_ids) {
+        T* b = w.hslab;
+        size_t n = w.capacity;
+        rtd::DHits<T> h{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, w.hmat, nullptr, nullptr, nullptr};
         if (with_ids) {
-            h.owner = hids.p;
-            h.sub = hids.p + n;
-            h.world_index = hids.p + 2 * n;
+            h.owner = w.hids;
+            h.sub = w.hids + n;
+            h.world_index = w.hids + 2 * n;
         }
         return h;
     }
     // k_extend.  World trees whose leaves are whole objects (no meshes) go to k_extend_refill: node steps
     // and object tests in separate phases, rays handed out from a launch-wide cursor (counts[1], zeroed
-    // here).  RT_REFILL=n: 0 = k_extend for every scene; n < 64 = lanes also take new rays while others of
-    // their wave still walk, as soon as n lanes wait (measured: slower).
+    // by the k_scan_tiles before).  RT_REFILL=n: 0 = k_extend for every scene; n < 64 = lanes also take new rays
+    // while others of their wave still walk, as soon as n lanes wait (measured: slower).
     int refill_lanes() const {
         int refill = 0;
         if (S.nodes4 && S.n_sweep == 0 && !small.blob) {
@@ -652,32 +817,36 @@ struct Engine : EngineBase {
         }
         return refill;
     }
-    void prepare_extend() {  // (before the launch's timing event)
-        if (refill_lanes() > 0) HIP_CHECK(hipMemsetAsync(counts.p + 1, 0, sizeof(uint32_t), stream));
-    }
-    void launch_extend(const rtd::DBatch& B, rtd::DQueue<T> q, rtd::DHits<T> h, const T* tmin, const T* tmax, uint32_t depth,
-                       uint32_t n_tiles, int grid) {
+    void launch_extend(const Work<T>& w, hipStream_t st, const rtd::DBatch& B, rtd::DQueue<T> q, rtd::DHits<T> h, const T* tmin,
+                       const T* tmax, uint32_t depth, uint32_t n_tiles, int grid) {
         const int refill = refill_lanes();
         if (refill > 0) grid = std::min(grid, num_cus * 4);
-        rtd::Launch<T>::extend(S, small, B, q, h, tmin, tmax, depth, tile_offsets.p, n_tiles, stack_depth, grid, counts.p + 1, refill, stream);
+        rtd::Launch<T>::extend(S, small, B, q, h, tmin, tmax, depth, w.tile_offsets, n_tiles, stack_depth, grid, w.counts + 1, refill, st);
     }
     static uint32_t tiles_for(size_t n) { return (uint32_t)((n + RT_TILE - 1) / RT_TILE); }
-    int grid_for(size_t n) {  // persistent blocks, grid-stride over the dense work index
+    int grid_for(size_t n, int lanes_running = 1) {  // persistent blocks, grid-stride over the dense work index
         size_t blocks = (n + 255) / 256;
         // Blocks per CU that stride over the dense work index.  4 are resident (128 VGPRs); handing the work out in
         // 32 pieces per CU instead of 8 lets the dispatcher even out blocks that finish at different times:
         // cornell 22.3 -> 21.1 ms, knight 48.6 -> 47.2, blocks_ball 20.2 -> 20.0 (4: 23.0 / 49.4 / 20.3; 16: 21.4 /
         // 47.5 / 20.1; 64: 21.1 / 48.3 / 19.9; 128: 21.2 / 49.6 / 19.9; one block per 256 rays: 22.1 / 51.4 / 19.9).
         // RT_GRID_MULT=n (environment) overrides for A/B runs.
+        static const bool grid_mult_forced = std::getenv("RT_GRID_MULT") != nullptr;
         static const size_t per_cu = [] {
             const char* e = std::getenv("RT_GRID_MULT");
             const long v = e ? std::strtol(e, nullptr, 10) : 0;
             return (size_t)(v > 0 && v <= 65536 ? v : 32);
         }();
-        size_t cap = (size_t)num_cus * per_cu;
+        // (two lanes share the CUs: 8 per CU each measured best, knight 45.2 -> 43.8 ms, cornell 19.7 -> 19.3)
+        size_t cap = (size_t)num_cus * (lanes_running > 1 && !grid_mult_forced ? 8 : per_cu);
         blocks = blocks < 1 ? 1 : blocks > cap ? cap : blocks;
         if (blocks > 8) blocks = (blocks + 7) & ~(size_t)7;  // whole groups of eight: k_extend's XCD-aware chunk order (a block without work leaves at once)
         return (int)blocks;
+    }
+    int tail_grid_for(size_t n) {  // the tail launch hands paths out from a cursor: no more blocks than stay resident (RT_TAIL_WAVES per SIMD)
+        size_t blocks = (n + 255) / 256;
+        const size_t cap = (size_t)num_cus * tail_blocks_per_cu;
+        return (int)(blocks < 1 ? 1 : blocks > cap ? cap : blocks);
     }
     void need_scene() {
         if (!have_scene) throw RtError{RT_ERR_NO_SCENE, "no scene uploaded (call rt_upload_scene first)"};
@@ -686,22 +855,23 @@ struct Engine : EngineBase {
     void trace(const rt_ray* rays, size_t n, uint64_t seed, rt_hit* out) override {
         need_scene();
         static_assert(sizeof(rt_ray) == 9 * sizeof(double), "rt_ray layout");
+        Lane<T>& L = *lanes[0];
         size_t chunk_max = (size_t)std::min<uint64_t>(max_paths, 1u << 24);
         for (size_t base = 0; base < n; base += chunk_max) {
             size_t m = std::min(chunk_max, n - base);
-            ensure_capacity(m, true);
+            L.ensure(m, 0, true);
+            const Work<T>& w = L.w;
             io_f64.ensure(m * 9);
             io_hits.ensure(m);
             HIP_CHECK(hipMemcpyAsync(io_f64.p, rays + base, m * sizeof(rt_ray), hipMemcpyHostToDevice, stream));
             rtd::DBatch B{0, 0, 0, 1, (uint32_t)base, 1u, seed};
-            rtd::DQueue<T> q = queue(0);
-            rtd::DHits<T> h = hits(true);
-            T* tmin = tminmax.p;
-            T* tmax = tminmax.p + capacity;
-            rtd::Launch<T>::load_rays(io_f64.p, (uint32_t)m, q, tmin, tmax, tile_counts[0].p, stream);
-            rtd::launch_scan_tiles(tile_counts[0].p, tiles_for(m), tile_offsets.p, nullptr, counts.p, nullptr, stream);
-            prepare_extend();
-            launch_extend(B, q, h, tmin, tmax, 0, tiles_for(m), grid_for(m));
+            rtd::DQueue<T> q = queue(w, 0);
+            rtd::DHits<T> h = hits(w, true);
+            T* tmin = w.tminmax;
+            T* tmax = w.tminmax + w.capacity;
+            rtd::Launch<T>::load_rays(io_f64.p, (uint32_t)m, q, tmin, tmax, w.tile_counts[0], stream);
+            rtd::launch_scan_tiles(w.tile_counts[0], tiles_for(m), w.tile_offsets, nullptr, w.counts, nullptr, nullptr, stream);
+            launch_extend(w, stream, B, q, h, tmin, tmax, 0, tiles_for(m), grid_for(m));
             rtd::Launch<T>::store_hits(q, h, (uint32_t)m, io_hits.p, stream);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipMemcpyAsync(out + base, io_hits.p, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
@@ -714,155 +884,305 @@ struct Engine : EngineBase {
         size_t n = (size_t)W * (j1 - j0);
         if (n == 0) return;
         if (n > max_paths) throw RtError{RT_ERR_INVALID, "rt_primary_rays: band larger than max_paths"};
-        ensure_capacity(n, false);
+        Lane<T>& L = *lanes[0];
+        L.ensure(n, 0, false);
         io_f64.ensure(n * 9);
         rtd::DBatch B{W, H, j0, (uint32_t)n, sample, 0u, seed};
-        rtd::DQueue<T> q = queue(0);
-        rtd::Launch<T>::raygen(S, B, q, (uint32_t)n, tile_counts[0].p, stream);
+        rtd::DQueue<T> q = queue(L.w, 0);
+        rtd::Launch<T>::raygen(S, B, q, (uint32_t)n, L.w.tile_counts[0], stream);
         rtd::Launch<T>::store_rays(q, (uint32_t)n, io_f64.p, stream);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(out, io_f64.p, n * sizeof(rt_ray), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 
-    hipEvent_t event(size_t k) {
-        while (events.size() <= k) {
-            hipEvent_t e;
-            HIP_CHECK(hipEventCreate(&e));
-            events.push_back(e);
-        }
-        return events[k];
-    }
+    // ---- the render loop.  A call's samples are cut into batches (sample ranges, in order); batch i runs on lane
+    // i % K: raygen -> [extend -> shade | bounce] x bounces -> (tail launch) -> accumulate.  The host never waits
+    // for a stream inside a batch: every k_scan_tiles stores the live count of its bounce in pinned memory, the host
+    // reads what has arrived (RUNAHEAD bounces late at most) and uses it to stop when the paths are dead, to size the
+    // grids and to start the tail launch; launches that find their queue empty leave at once.  k_accumulate of batch
+    // i waits for that of batch i - 1 (an event), so that the sums are added in sample order whatever the lane count:
+    // the image does not depend on K bit for bit.
+    struct Span {
+        size_t first;  // event index
+        int kind;      // 0 = extend / 1 = shade / 2 = tail launch next to k_extend
+    };
+    struct BatchRun {
+        bool active = false;
+        uint32_t index = 0, bs0 = 0, bns = 0, n_paths = 0, n_tiles = 0, depth = 0, known_depth = 0, known_alive = 0;
+        rtd::DBatch B;
+    };
+    struct LaneRun {
+        Lane<T>* lane = nullptr;
+        BatchRun b;
+        uint32_t next_batch = 0;  // next batch index this lane takes
+        bool done = false;
+        size_t ev = 0;
+        std::vector<Span> spans;
+        uint32_t n_extend = 0, n_shade = 0, n_tail = 0;  // launches (counted whether or not they are timed)
+        uint32_t deepest = 0;
+    };
+    enum StepResult { STEP_PROGRESS, STEP_BLOCKED, STEP_DONE };
 
     void render_accum(uint32_t W, uint32_t H, uint32_t j0, uint32_t j1, uint32_t s0, uint32_t ns, uint32_t max_bounces,
-                      uint64_t seed, double* accum_dev, rt_stats* stats) override {
+                      uint64_t seed, double* accum_dev, rt_stats* stats, bool fixed) override {
         need_scene();
         if (stats) std::memset(stats, 0, sizeof(*stats));
-        uint64_t npix = (uint64_t)W * (j1 - j0);
+        const uint64_t npix = (uint64_t)W * (j1 - j0);
         if (npix == 0 || ns == 0) return;
-        if (npix > max_paths || npix > 0xffffffffull)
+        if (fixed && !fixed_lane) throw RtError{RT_ERR_UNSUPPORTED, "the static work area is not available on this device"};
+        // Lanes: a second stream pays when each lane still gets a large batch (600 px, 100 spp: cornell 20.65 -> 19.3 ms,
+        // knight 46.1 -> 43.8, blocks_ball 19.5 -> 18.7; at 13 spp the halves are too small and it loses 3 - 20 %), and
+        // a band that fills the path budget leaves no room for a second lane's queues.  RT_LANE_MIN_PATHS overrides.
+        static const uint64_t lane_min_paths = [] {
+            const char* e = std::getenv("RT_LANE_MIN_PATHS");
+            return e ? (uint64_t)std::strtoull(e, nullptr, 10) : (uint64_t)8 << 20;
+        }();
+        const int K = fixed ? 1
+                            : (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(lanes.size(), max_paths / npix),
+                                                                             npix * ns / std::max<uint64_t>(1, lane_min_paths)));
+        const uint64_t lane_paths = fixed ? (uint64_t)RT_NOALLOC_MAX_PATHS : std::max<uint64_t>(1, max_paths / (uint64_t)K);
+        if (npix > lane_paths || npix > 0xffffffffull) {
+            if (fixed)
+                throw RtError{RT_ERR_INVALID, "rt_render_accum_device_noalloc: the row band holds more than " +
+                                                  std::to_string(RT_NOALLOC_MAX_PATHS) + " pixels (the static work area's size); render fewer rows per call"};
             throw RtError{RT_ERR_INVALID, "row band holds more pixels than max_paths; render fewer rows per call"};
-        uint64_t spb_cap = std::max<uint64_t>(1, max_paths / npix);
+        }
+        // batches: whole samples of every pixel of the band; at least one per lane when there are samples enough
+        const uint64_t spb_cap = std::max<uint64_t>(1, lane_paths / npix);
         uint32_t n_batches = (uint32_t)((ns + spb_cap - 1) / spb_cap);
-        uint32_t spb = (ns + n_batches - 1) / n_batches;
-        ensure_capacity((size_t)(npix * spb), false);
-        sample_rgb.ensure((size_t)(npix * spb) * 3);
-        HIP_CHECK(hipMemsetAsync(ray_total.p, 0, 2 * sizeof(unsigned long long), stream));
-        HIP_CHECK(hipMemsetAsync(counts.p + 2, 0, sizeof(uint32_t), stream));
-        size_t ev = 0;
-        const bool timing = stats != nullptr;
+        n_batches = std::max(n_batches, std::min<uint32_t>((uint32_t)K, ns));
+        const uint32_t spb = (ns + n_batches - 1) / n_batches;
+        n_batches = (ns + spb - 1) / spb;
+        const bool timing = stats != nullptr && time_launches && !fixed;
         // One fused launch per bounce pays off when the traversal is the lean sweep (no stack, no spills:
         // cornell 30.5 -> 25.2 ms); with a divergent tree walk the shading half runs at the walk's low
         // occupancy and loses (knight 95 -> 107 ms).  RT_FUSE=0 / 1 (environment) overrides for A/B runs.
         const bool debug_counts = std::getenv("RT_DEBUG") != nullptr;
         const char* fuse_env = std::getenv("RT_FUSE");
         const bool fused = fuse_env ? fuse_env[0] != '0' : (S.n_sweep > 0 && S.lean);
-        // Paths alive at or below which the tail launch takes over (RT_TAIL=n in the environment overrides, 0: never);
-        // measured: knight 78.8 / 69.0 / 67.0 / 68.5 ms at 0 / 64 k / 128 k / 600 k, cornell 24.85 / 24.7 / 24.4 / 24.2
-        // The host looks at the live count every peek_every-th bounce (RT_PEEK=n in the environment overrides).
-        uint32_t peek_every = 4;
-        if (const char* e = std::getenv("RT_PEEK")) peek_every = (uint32_t)std::max(1l, std::strtol(e, nullptr, 10));
-        uint32_t tail_threshold = fused ? 524288u : 131072u;
+        // Paths alive at or below which the tail launch takes over (RT_TAIL=n in the environment overrides, 0: never).
+        // The tail launch hands its paths out from a cursor, so it stays efficient with many more paths than are
+        // resident at a time; what it saves is the wait for the slowest ray of every bounce.
+        uint32_t tail_threshold = fused ? tail_threshold_fused : tail_threshold_tree;
         if (const char* e = std::getenv("RT_TAIL")) tail_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
-        std::vector<std::pair<size_t, int>> spans;  // (first event index, 0 = extend / 1 = shade / 2 = tail launch next to k_extend)
-        uint64_t tail_first_bounce = 0;
-        hipEvent_t ev_begin = event(ev++), ev_end = event(ev++);
-        if (timing) HIP_CHECK(hipEventRecord(ev_begin, stream));
-        uint32_t deepest = 0;
-        for (uint32_t b = 0; b < n_batches; b++) {
-            uint32_t bs0 = s0 + b * spb;
-            uint32_t bns = std::min(spb, s0 + ns - bs0);
-            uint32_t n_paths = (uint32_t)(npix * bns);
-            rtd::DBatch B{W, H, j0, (uint32_t)npix, bs0, 0u, seed};
-            HIP_CHECK(hipMemsetAsync(sample_rgb.p, 0, (size_t)n_paths * 3 * sizeof(T), stream));
-            rtd::Launch<T>::raygen(S, B, queue(0), n_paths, tile_counts[0].p, stream);
-            int grid = grid_for(n_paths);
-            uint32_t n_tiles = tiles_for(n_paths);
-            // offsets of queue 0, clear the counts of queue 1, rays += n_paths (if any bounce runs)
-            rtd::launch_scan_tiles(tile_counts[0].p, n_tiles, tile_offsets.p, tile_counts[1].p, counts.p,
-                                   max_bounces ? ray_total.p : nullptr, stream);
-            for (uint32_t depth = 0; depth < max_bounces; depth++) {
-                int in = depth & 1, out = in ^ 1;
-                if (!fused) prepare_extend();
-                if (timing) {
-                    spans.push_back({ev, 0});
-                    HIP_CHECK(hipEventRecord(event(ev), stream));
-                }
-                if (fused) {  // one launch per bounce; its time is reported as ms_extend
-                    rtd::Launch<T>::bounce(S, small, B, queue(in), queue(out), sample_rgb.p, depth, max_bounces,
-                                           tile_offsets.p, tile_counts[out].p, n_tiles, stack_depth, grid, nullptr, stream);
-                    if (timing) HIP_CHECK(hipEventRecord(event(ev + 1), stream));
-                } else {
-                    launch_extend(B, queue(in), hits(false), nullptr, nullptr, depth, n_tiles, grid);
-                    if (timing) {
-                        HIP_CHECK(hipEventRecord(event(ev + 1), stream));
-                        spans.push_back({ev + 1, 1});
-                    }
-                    rtd::Launch<T>::shade(S, B, queue(in), hits(false), queue(out), sample_rgb.p, depth, max_bounces,
-                                          tile_offsets.p, tile_counts[out].p, n_tiles, grid, stream);
-                }
-                // offsets of the queue just written, clear the counts of the other one, rays += survivors
-                rtd::launch_scan_tiles(tile_counts[out].p, n_tiles, tile_offsets.p, tile_counts[in].p, counts.p,
-                                       ray_total.p, stream);
-                if (timing) HIP_CHECK(hipEventRecord(event(ev + 2), stream));
-                ev += 3;
-                deepest = std::max(deepest, depth + 1);
-                if ((depth + 1) % peek_every == 0 && depth + 1 < max_bounces) {
-                    // Every 4th bounce: is anything still alive?  (One 4-byte read-back.)
-                    HIP_CHECK(hipMemcpyAsync(host_counts, counts.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                    HIP_CHECK(hipStreamSynchronize(stream));
-                    if (debug_counts) std::fprintf(stderr, "  after bounce %u: %u paths alive\n", depth + 1, host_counts[0]);
-                    if (host_counts[0] == 0) break;
-                    if (host_counts[0] <= tail_threshold) {
-                        // The few paths left go through all their remaining bounces in ONE launch, each at its
-                        // own pace, instead of one launch per bounce that waits for the slowest ray (k_bounce,
-                        // DTail).  Its time is reported with the extend kernel's.
-                        const rtd::DTail tail{ray_total.p + 1, counts.p + 2};
-                        tail_first_bounce += host_counts[0];
-                        if (timing) {
-                            spans.push_back({ev, fused ? 0 : 2});
-                            HIP_CHECK(hipEventRecord(event(ev), stream));
-                        }
-                        rtd::Launch<T>::bounce(S, small, B, queue(out), queue(in), sample_rgb.p, depth + 1, max_bounces,
-                                               tile_offsets.p, tile_counts[in].p, n_tiles, stack_depth, grid_for(host_counts[0]),
-                                               &tail, stream);
-                        if (timing) HIP_CHECK(hipEventRecord(event(ev + 1), stream));
-                        ev += 3;
-                        break;
-                    }
-                }
-            }
-            rtd::Launch<T>::accumulate(sample_rgb.p, (uint32_t)npix, bns, accum_dev, stream);
-            HIP_CHECK(hipGetLastError());
+        uint32_t runahead = 2;  // bounces enqueued beyond the last one whose live count the host has seen
+        if (const char* e = std::getenv("RT_RUNAHEAD")) runahead = (uint32_t)std::max(1l, std::min(64l, std::strtol(e, nullptr, 10)));
+
+        std::vector<LaneRun> runs((size_t)K);
+        for (int k = 0; k < K; k++) {
+            runs[k].lane = fixed ? fixed_lane.get() : lanes[(size_t)k].get();
+            runs[k].next_batch = (uint32_t)k;
+            if ((uint32_t)k >= n_batches) runs[k].done = true;
+            else runs[k].lane->ensure((size_t)(npix * spb), (size_t)(npix * spb), false);
         }
-        if (timing) HIP_CHECK(hipEventRecord(ev_end, stream));
-        unsigned long long totals[2] = {0, 0};
-        HIP_CHECK(hipMemcpyAsync(totals, ray_total.p, sizeof(totals), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(host_counts + 2, counts.p + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        deepest = std::max(deepest, std::min(host_counts[2], max_bounces));
-        if (stats) {
-            stats->rays = totals[0] + totals[1];
-            if (!fused) stats->rays_tail = tail_first_bounce + totals[1];
-            stats->extend_kernel = fused ? 2u : refill_lanes() > 0 ? 1u : 0u;
-            stats->paths = npix * ns;
-            stats->batches = n_batches;
-            stats->max_depth_reached = deepest;
+        Lane<T>& L0 = *runs[0].lane;
+        hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+        if (stats && !fixed) {
+            ev_begin = L0.event(runs[0].ev++);
+            ev_end = L0.event(runs[0].ev++);
+            HIP_CHECK(hipEventRecord(ev_begin, L0.stream));
+        }
+        // the other lanes start after what the caller has enqueued on the context's stream (e.g. the clearing of accum)
+        if (K > 1) {
+            HIP_CHECK(hipEventRecord(L0.ev_join, L0.stream));
+            for (int k = 1; k < K; k++)
+                if (!runs[k].done) HIP_CHECK(hipStreamWaitEvent(runs[k].lane->stream, L0.ev_join, 0));
+        }
+        for (int k = 0; k < K; k++) {
+            if (runs[k].done) continue;
+            const Work<T>& w = runs[k].lane->w;
+            HIP_CHECK(hipMemsetAsync(w.ray_total, 0, 3 * sizeof(unsigned long long), runs[k].lane->stream));
+            HIP_CHECK(hipMemsetAsync(w.counts + 2, 0, sizeof(uint32_t), runs[k].lane->stream));
+        }
+        uint32_t acc_recorded = 0;  // batches whose k_accumulate has been enqueued (they are enqueued in batch order)
+
+        auto finish_batch = [&](LaneRun& R) -> bool {
+            if (acc_recorded != R.b.index) return false;  // the batch before has not enqueued its k_accumulate yet
+            Lane<T>& L = *R.lane;
+            if (R.b.index > 0 && K > 1) {
+                Lane<T>& prev = *runs[(size_t)((R.b.index - 1) % (uint32_t)K)].lane;
+                HIP_CHECK(hipStreamWaitEvent(L.stream, prev.ev_acc, 0));
+            }
+            rtd::Launch<T>::accumulate(L.w.sample_rgb, (uint32_t)npix, R.b.bns, accum_dev, L.stream);
+            HIP_CHECK(hipGetLastError());
+            if (K > 1) HIP_CHECK(hipEventRecord(L.ev_acc, L.stream));
+            acc_recorded++;
+            R.b.active = false;
+            R.next_batch += (uint32_t)K;
+            return true;
+        };
+
+        auto step = [&](LaneRun& R) -> StepResult {
+            if (R.done) return STEP_DONE;
+            Lane<T>& L = *R.lane;
+            const Work<T>& w = L.w;
+            hipStream_t st = L.stream;
+            BatchRun& b = R.b;
+            if (!b.active) {
+                if (R.next_batch >= n_batches) {
+                    R.done = true;
+                    return STEP_DONE;
+                }
+                b.index = R.next_batch;
+                b.bs0 = s0 + b.index * spb;
+                b.bns = std::min(spb, s0 + ns - b.bs0);
+                b.n_paths = (uint32_t)(npix * b.bns);
+                b.n_tiles = tiles_for(b.n_paths);
+                b.B = rtd::DBatch{W, H, j0, (uint32_t)npix, b.bs0, 0u, seed};
+                b.depth = 0;
+                b.known_depth = 0;
+                b.known_alive = b.n_paths;
+                b.active = true;
+                for (uint32_t k = 0; k < PEEK_SLOTS; k++) L.peek[k] = PEEK_UNKNOWN;
+                __atomic_thread_fence(__ATOMIC_SEQ_CST);
+                HIP_CHECK(hipMemsetAsync(w.sample_rgb, 0, (size_t)b.n_paths * 3 * sizeof(T), st));
+                rtd::Launch<T>::raygen(S, b.B, queue(w, 0), b.n_paths, w.tile_counts[0], st);
+                // offsets of queue 0, clear the counts of queue 1, rays += n_paths (if any bounce runs)
+                rtd::launch_scan_tiles(w.tile_counts[0], b.n_tiles, w.tile_offsets, w.tile_counts[1], w.counts,
+                                       max_bounces ? w.ray_total : nullptr, nullptr, st);
+                return STEP_PROGRESS;
+            }
+            // what the kernels have told us so far
+            while (b.known_depth < b.depth) {
+                const uint32_t v = L.peek_value(b.known_depth + 1);
+                if (v == PEEK_UNKNOWN) break;
+                b.known_depth++;
+                b.known_alive = v;
+                if (debug_counts) std::fprintf(stderr, "  batch %u after bounce %u: %u paths alive\n", b.index, b.known_depth, v);
+            }
+            if (b.known_alive == 0 || b.depth >= max_bounces) return finish_batch(R) ? STEP_PROGRESS : STEP_BLOCKED;
+            if (b.depth - b.known_depth > runahead) return STEP_BLOCKED;
+            const uint32_t depth = b.depth;
+            const int in = (int)(depth & 1u), out = in ^ 1;
+            if (b.known_alive <= tail_threshold) {
+                // The paths that are left go through all their remaining bounces in ONE launch, each at its own
+                // pace, instead of one launch per bounce that waits for the slowest ray (k_bounce, DTail).  The
+                // count is RUNAHEAD bounces old at most, i.e. an upper bound of what the launch will find.
+                const rtd::DTail tail{w.ray_total + 1, w.counts + 2, w.counts + 3};
+                if (fused) R.n_extend++;
+                else R.n_tail++;
+                if (timing) {
+                    R.spans.push_back({R.ev, fused ? 0 : 2});
+                    HIP_CHECK(hipEventRecord(L.event(R.ev), st));
+                }
+                rtd::Launch<T>::bounce(S, small, b.B, queue(w, in), queue(w, out), w.sample_rgb, depth, max_bounces, w.tile_offsets,
+                                       w.tile_counts[out], b.n_tiles, stack_depth, tail_grid_for(b.known_alive), &tail, st);
+                if (timing) HIP_CHECK(hipEventRecord(L.event(R.ev + 1), st));
+                R.ev += 3;
+                b.depth = max_bounces;  // nothing is left after it
+                b.known_alive = 0;
+                return STEP_PROGRESS;
+            }
+            const int grid = grid_for(b.known_alive, K);
+            R.n_extend++;
+            if (!fused) R.n_shade++;
+            if (timing) {
+                R.spans.push_back({R.ev, 0});
+                HIP_CHECK(hipEventRecord(L.event(R.ev), st));
+            }
+            if (fused) {  // one launch per bounce; its time is reported as ms_extend
+                rtd::Launch<T>::bounce(S, small, b.B, queue(w, in), queue(w, out), w.sample_rgb, depth, max_bounces, w.tile_offsets,
+                                       w.tile_counts[out], b.n_tiles, stack_depth, grid, nullptr, st);
+                if (timing) HIP_CHECK(hipEventRecord(L.event(R.ev + 1), st));
+            } else {
+                launch_extend(w, st, b.B, queue(w, in), hits(w, false), nullptr, nullptr, depth, b.n_tiles, grid);
+                if (timing) {
+                    HIP_CHECK(hipEventRecord(L.event(R.ev + 1), st));
+                    R.spans.push_back({R.ev + 1, 1});
+                }
+                rtd::Launch<T>::shade(S, b.B, queue(w, in), hits(w, false), queue(w, out), w.sample_rgb, depth, max_bounces,
+                                      w.tile_offsets, w.tile_counts[out], b.n_tiles, grid, st);
+            }
+            // offsets of the queue just written, clear the counts of the other one, rays += survivors, and the
+            // live count to the host
+            L.peek[(depth + 1) % PEEK_SLOTS] = PEEK_UNKNOWN;
+            __atomic_thread_fence(__ATOMIC_SEQ_CST);
+            rtd::launch_scan_tiles(w.tile_counts[out], b.n_tiles, w.tile_offsets, w.tile_counts[in], w.counts, w.ray_total,
+                                   L.peek_dev() + (depth + 1) % PEEK_SLOTS, st);
+            if (timing) HIP_CHECK(hipEventRecord(L.event(R.ev + 2), st));
+            if (timing) R.ev += 3;
+            R.deepest = std::max(R.deepest, depth + 1);
+            b.depth = depth + 1;
+            return STEP_PROGRESS;
+        };
+
+        uint64_t idle_spins = 0;
+        uint32_t idle_checks = 0;
+        for (;;) {
+            bool all_done = true, progressed = false;
+            for (int k = 0; k < K; k++) {
+                const StepResult r = step(runs[(size_t)k]);
+                if (r != STEP_DONE) all_done = false;
+                if (r == STEP_PROGRESS) progressed = true;
+            }
+            if (all_done) break;
+            if (!progressed) {
+                // every lane waits for a live count: the streams are RUNAHEAD bounces ahead of what we know.  Now and
+                // then make sure that they are still running (a count that never arrives must not hang the host).
+                if (++idle_spins % 4096 == 0) {
+                    bool busy = false;
+                    for (int k = 0; k < K; k++) {
+                        const hipError_t e = hipStreamQuery(runs[(size_t)k].lane->stream);
+                        if (e == hipErrorNotReady) {
+                            busy = true;
+                            (void)hipGetLastError();
+                        } else if (e != hipSuccess) {
+                            throw RtError{RT_ERR_DEVICE, std::string("render stream failed: ") + hipGetErrorString(e)};
+                        }
+                    }
+                    if (!busy && ++idle_checks > 64) throw RtError{RT_ERR_DEVICE, "internal: a live count never arrived from the device"};
+                }
+                __builtin_ia32_pause();
+            } else {
+                idle_checks = 0;
+            }
+        }
+        // join: the context's stream continues after every lane
+        for (int k = 1; k < K; k++) {
+            if (runs[(size_t)k].next_batch == (uint32_t)k) continue;  // never ran
+            HIP_CHECK(hipEventRecord(runs[(size_t)k].lane->ev_join, runs[(size_t)k].lane->stream));
+            HIP_CHECK(hipStreamWaitEvent(L0.stream, runs[(size_t)k].lane->ev_join, 0));
+        }
+        if (ev_end) HIP_CHECK(hipEventRecord(ev_end, L0.stream));
+        for (int k = 0; k < K; k++) {
+            LaneRun& R = runs[(size_t)k];
+            if (R.next_batch == (uint32_t)k) continue;
+            const Work<T>& w = R.lane->w;
+            R.lane->readback[3] = 0;
+            HIP_CHECK(hipMemcpyAsync(R.lane->readback, w.ray_total, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.lane->stream));
+            HIP_CHECK(hipMemcpyAsync(R.lane->readback + 3, w.counts + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, R.lane->stream));
+        }
+        for (int k = K - 1; k >= 0; k--) HIP_CHECK(hipStreamSynchronize(runs[(size_t)k].lane->stream));
+        if (!stats) return;
+        uint32_t deepest = 0;
+        for (int k = 0; k < K; k++) {
+            LaneRun& R = runs[(size_t)k];
+            if (R.next_batch == (uint32_t)k) continue;
+            stats->rays += R.lane->readback[0] + R.lane->readback[1];
+            if (!fused) stats->rays_tail += R.lane->readback[1] + R.lane->readback[2];
+            deepest = std::max(deepest, std::min(std::max(R.deepest, (uint32_t)R.lane->readback[3]), max_bounces));
+            stats->extend_launches += R.n_extend;
+            stats->shade_launches += R.n_shade;
+            stats->tail_launches += R.n_tail;
+        }
+        stats->extend_kernel = fused ? 2u : refill_lanes() > 0 ? 1u : 0u;
+        stats->paths = npix * ns;
+        stats->batches = n_batches;
+        stats->max_depth_reached = deepest;
+        if (ev_begin) {
             float ms = 0;
             HIP_CHECK(hipEventElapsedTime(&ms, ev_begin, ev_end));
             stats->ms_total = ms;
-            for (auto& sp : spans) {
-                HIP_CHECK(hipEventElapsedTime(&ms, events[sp.first], events[sp.first + 1]));
-                if (sp.second == 0) {
-                    stats->ms_extend += ms;
-                    stats->extend_launches++;
-                } else if (sp.second == 2) {
-                    stats->ms_tail += ms;
-                    stats->tail_launches++;
-                } else {
-                    stats->ms_shade += ms;
-                    stats->shade_launches++;
-                }
+        }
+        for (int k = 0; k < K; k++) {
+            LaneRun& R = runs[(size_t)k];
+            for (auto& sp : R.spans) {
+                float ms = 0;
+                HIP_CHECK(hipEventElapsedTime(&ms, R.lane->events[sp.first], R.lane->events[sp.first + 1]));
+                if (sp.kind == 0) stats->ms_extend += ms;
+                else if (sp.kind == 2) stats->ms_tail += ms;
+                else stats->ms_shade += ms;
             }
         }
     }
@@ -891,6 +1211,19 @@ namespace rt {
 void set_global_error(const std::string& msg) { g_error = msg; }
 }  // namespace rt
 
+// Makes `device` current for the calling thread and puts the caller's device back on the way out.
+struct DeviceScope {
+    int before = -1;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&before) != hipSuccess) before = -1;
+        if (before != device) HIP_CHECK(hipSetDevice(device));
+        else before = -1;
+    }
+    ~DeviceScope() {
+        if (before >= 0) (void)hipSetDevice(before);
+    }
+};
+
 template <typename F>
 static int guard_global(F&& f) {
     try {
@@ -918,7 +1251,7 @@ static int guard(rt_context* ctx, F&& f) {
         return RT_ERR_INVALID;
     }
     int rc = guard_global([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        DeviceScope scope(ctx->device);
         f();
     });
     if (rc != RT_OK) ctx->error = g_error;
@@ -976,7 +1309,7 @@ int rt_create(int device_id, const rt_options* options, rt_context** out) {
         if (e != hipSuccess || count == 0)
             throw RtError{RT_ERR_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e)};
         if (device_id < 0 || device_id >= count) throw RtError{RT_ERR_INVALID, "rt_create: device id out of range"};
-        HIP_CHECK(hipSetDevice(device_id));
+        DeviceScope scope(device_id);
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
         std::unique_ptr<rt_context> ctx(new rt_context);
@@ -985,10 +1318,14 @@ int rt_create(int device_id, const rt_options* options, rt_context** out) {
         int precision = options ? options->precision : RT_PRECISION_F64;
         uint64_t max_paths = options && options->max_paths ? options->max_paths : (1ull << 25);
         if (max_paths > 0xffffffffull) max_paths = 0xffffffffull;
+        // lanes: streams (each with its own queues) that share a call's batches; RT_LANES in the environment overrides
+        int n_lanes = options && options->lanes > 0 ? options->lanes : RT_DEFAULT_LANES;
+        if (const char* e = std::getenv("RT_LANES")) n_lanes = (int)std::strtol(e, nullptr, 10);
+        n_lanes = std::max(1, std::min(8, n_lanes));
         if (precision == RT_PRECISION_F64)
-            ctx->engine.reset(new Engine<double>(ctx->stream, prop.multiProcessorCount, max_paths));
+            ctx->engine.reset(new Engine<double>(ctx->stream, prop.multiProcessorCount, max_paths, n_lanes, nullptr, 0));
         else if (precision == RT_PRECISION_F32)
-            ctx->engine.reset(new Engine<float>(ctx->stream, prop.multiProcessorCount, max_paths));
+            ctx->engine.reset(new Engine<float>(ctx->stream, prop.multiProcessorCount, max_paths, n_lanes, nullptr, 0));
         else
             throw RtError{RT_ERR_INVALID, "rt_create: unknown precision"};
         ctx->max_paths = max_paths;
@@ -998,12 +1335,26 @@ int rt_create(int device_id, const rt_options* options, rt_context** out) {
 
 void rt_destroy(rt_context* ctx) {
     if (!ctx) return;
+    int before = -1;
+    if (hipGetDevice(&before) != hipSuccess) before = -1;
     (void)hipSetDevice(ctx->device);
     ctx->engine.reset();
     ctx->tmp_accum.release();
     ctx->tmp_rgb8.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (before >= 0) (void)hipSetDevice(before);
     delete ctx;
+}
+
+int rt_set_launch_timing(rt_context* ctx, int on) {
+    return guard(ctx, [&] { ctx->engine->set_launch_timing(on != 0); });
+}
+
+int rt_get_upload_stats(rt_context* ctx, rt_upload_stats* out) {
+    return guard(ctx, [&] {
+        if (!out) throw RtError{RT_ERR_INVALID, "rt_get_upload_stats: null out pointer"};
+        ctx->engine->upload_stats(out);
+    });
 }
 
 const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
@@ -1039,7 +1390,7 @@ int rt_render_accum_device(rt_context* ctx, uint32_t width, uint32_t height, uin
             throw RtError{RT_ERR_INVALID, "rt_render_accum_device: bad image geometry (width, height >= 2, j0 <= j1 <= height)"};
         if (!accum_dev && j1 > j0 && n_samples) throw RtError{RT_ERR_INVALID, "rt_render_accum_device: null accum buffer"};
         if ((uint64_t)s0 + n_samples > 0xffffffffull) throw RtError{RT_ERR_INVALID, "sample index overflow"};
-        ctx->engine->render_accum(width, height, j0, j1, s0, n_samples, max_bounces, seed, accum_dev, stats);
+        ctx->engine->render_accum(width, height, j0, j1, s0, n_samples, max_bounces, seed, accum_dev, stats, false);
     });
 }
 
@@ -1070,7 +1421,7 @@ int rt_render_rows(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0
             uint32_t b1 = std::min(j1, b0 + rows_per_band);
             rt_stats part;
             ctx->engine->render_accum(width, height, b0, b1, 0, spp, max_bounces, seed,
-                                      ctx->tmp_accum.p + (uint64_t)(b0 - j0) * width * 3, stats ? &part : nullptr);
+                                      ctx->tmp_accum.p + (uint64_t)(b0 - j0) * width * 3, stats ? &part : nullptr, false);
             if (stats) {
                 stats->rays += part.rays; stats->paths += part.paths;
                 stats->ms_total += part.ms_total; stats->ms_extend += part.ms_extend; stats->ms_shade += part.ms_shade;

@@ -14,9 +14,18 @@
 //
 // Compiled with -ffp-contract=off: rustc never contracts a*b+c, and the f64 instantiation
 // follows the reference's operation order so that it walks the same paths as the oracle.
+//
+// The file is compiled once per RT_PART (0-5: extend / bounce / the rest, for double and for float; Makefile)
+// so that the six groups of kernel instantiations build in parallel; without RT_PART everything is one unit.
 #include "rt_device.h"
 
 #include "../../../include/rt_mi355x.h"
+
+#ifdef RT_PART
+#define RT_PART_HAS(n) (RT_PART == (n))
+#else
+#define RT_PART_HAS(n) 1
+#endif
 
 namespace rtd {
 
@@ -1120,11 +1129,13 @@ __device__ __forceinline__ uint32_t slot_of(const uint32_t* __restrict__ offsets
 // One block: exclusive scan of the per-tile counts of the queue that is read next; also
 // clears the counts of the queue that is written next and keeps the global totals.
 constexpr int SCAN_THREADS = 1024;
+#if RT_PART_HAS(2)
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_tiles(const uint32_t* __restrict__ tile_counts, uint32_t n_tiles,
                                                               uint32_t* __restrict__ tile_offsets,
                                                               uint32_t* __restrict__ counts_to_zero,
                                                               uint32_t* __restrict__ total_out,
-                                                              unsigned long long* __restrict__ ray_total) {
+                                                              unsigned long long* __restrict__ ray_total,
+                                                              uint32_t* __restrict__ host_total) {
     __shared__ uint32_t partial[SCAN_THREADS];
     const uint32_t per = (n_tiles + SCAN_THREADS - 1) / SCAN_THREADS;
     const uint32_t begin = min(n_tiles, threadIdx.x * per), end = min(n_tiles, begin + per);
@@ -1147,10 +1158,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_tiles(const uint32_t* __r
     if (threadIdx.x == SCAN_THREADS - 1) {
         uint32_t total = partial[SCAN_THREADS - 1];
         tile_offsets[n_tiles] = total;
-        *total_out = total;
+        total_out[0] = total;
+        total_out[1] = 0;  // k_extend_refill's cursor
+        total_out[3] = 0;  // the tail launch's cursor
         if (ray_total) *ray_total += total;  // every live entry becomes one closest-hit query
+        // the host follows the live count through pinned memory, without waiting for the stream
+        if (host_total) __hip_atomic_store(host_total, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+#endif
 
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<T> q, uint32_t n_paths,
@@ -1746,63 +1762,116 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? RT_TAIL_WAVES : RT_EXTEND_WA
     __shared__ uint4 lds_scene[LDS_SCENE ? RT_LDS_SCENE_BYTES / 16 : 1];
     int32_t stack_spill[StackFor<MODE>::SPILL];
     typename StackFor<MODE>::type st = StackFor<MODE>::make(lds_stack + threadIdx.x, S.stack_cap > 0 && S.stack_cap < STACK ? S.stack_cap : STACK, stack_spill);
-    // tail.run: the few paths that are left are carried through ALL their remaining bounces here, each at
-    // its own pace (a launch per bounce would wait for the slowest ray of every bounce: on the knight
-    // ~0.4 ms per bounce for a ray caught inside the glass mesh, 35 times over).  Same streams, same
-    // arithmetic, same image.
+    // tail.ray_total != nullptr: the paths that are left are carried through ALL their remaining bounces here, each
+    // at its own pace (a launch per bounce would wait for the slowest ray of every bounce: on the knight ~0.5 ms per
+    // bounce for a ray that grazes the mesh, 40 times over).  Same streams, same arithmetic, same image.
     const bool run_tail = CAN_TAIL && tail.ray_total != nullptr;
-    uint32_t extra_queries = 0, deepest = depth0;
     DScene<T> W = S;  // the traversal's view of the scene (records in LDS for small worlds)
     if (LDS_SCENE) stage_small_scene(W, small, lds_scene);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t total = tile_offsets[n_tiles];
-    for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < total; base += gridDim.x * BLOCK) {
-        const uint32_t d = base + lane;
-        const bool valid = d < total;
-        uint32_t tile = 0;
-        const uint32_t i = valid ? slot_of(tile_offsets, n_tiles, d, base, &tile) : 0u;
-        bool alive = false;
-        Ray<T> nr;
-        V3<T> thr;
-        uint32_t pid = 0;
-        if (valid) {
-            Ray<T> ray = load_ray(qin, i);
-            pid = qin.pid[i];
-            const PathRef path{&B, pid};
-            thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
-            deepest = depth0 + 1;
-            for (uint32_t depth = depth0;; depth++) {
-                T t = 0, u = 0, v = 0;
-                V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
-                uint32_t mf = RT_MISS;
-                Winner w;
-                if (closest_hit<T, MODE>(W, ray, (T)0.001, Lim<T>::inf(), st, path, depth, &t, &w)) {  // src/hitting.rs:20-21
+    // One bounce of one path: the closest-hit query, the hit record, the shading.
+    auto bounce_once = [&](const Ray<T>& ray, V3<T>& thr, uint32_t pid, uint32_t depth, Ray<T>& nr) -> bool {
+        const PathRef path{&B, pid};
+        T t = 0, u = 0, v = 0;
+        V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
+        uint32_t mf = RT_MISS;
+        Winner w;
+        if (closest_hit<T, MODE>(W, ray, (T)0.001, Lim<T>::inf(), st, path, depth, &t, &w)) {  // src/hitting.rs:20-21
 #if defined(RT_EXP) && (RT_EXP & 16)  // timing experiment only: no surface reconstruction
-                    n = mk((T)0.0, (T)1.0, (T)0.0);
-                    mf = (uint32_t)W.rects[w.prim].material | 0x80000000u;
+            n = mk((T)0.0, (T)1.0, (T)0.0);
+            mf = (uint32_t)W.rects[w.prim].material | 0x80000000u;
 #else
-                    const Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(W, ray, t, w, S.needs_uv != 0);
-                    n = sf.normal; u = sf.u; v = sf.v;
-                    mf = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
+            const Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(W, ray, t, w, S.needs_uv != 0);
+            n = sf.normal; u = sf.u; v = sf.v;
+            mf = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
 #endif
-                }
-                alive = shade_path<T, MODE != WALK_SWEEP_LEAN>(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
-                if (!run_tail || !alive) break;
-                ray = nr;  // the scattered ray is the next bounce's query
-                extra_queries++;
-                deepest = depth + 2;
-            }
-            if (run_tail) alive = false;
         }
-        compact_store(alive, tile, nr, thr, pid, qout, tile_counts_out);
+        return shade_path<T, MODE != WALK_SWEEP_LEAN>(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
+    };
+    if (!run_tail) {
+        for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < total; base += gridDim.x * BLOCK) {
+            const uint32_t d = base + lane;
+            const bool valid = d < total;
+            uint32_t tile = 0;
+            const uint32_t i = valid ? slot_of(tile_offsets, n_tiles, d, base, &tile) : 0u;
+            bool alive = false;
+            Ray<T> nr;
+            V3<T> thr;
+            uint32_t pid = 0;
+            if (valid) {
+                const Ray<T> ray = load_ray(qin, i);
+                pid = qin.pid[i];
+                thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
+                alive = bounce_once(ray, thr, pid, depth0, nr);
+            }
+            compact_store(alive, tile, nr, thr, pid, qout, tile_counts_out);
+        }
+        return;
     }
-    if (run_tail) {  // rays and depth statistics of the bounces that were not launches
+    if constexpr (CAN_TAIL) {
+        // The paths are handed out from a launch-wide cursor, a share of CHUNK at a time per wave (one atomic per
+        // share: every wave of the launch shares the cursor, and atomics on one address are served one by one); a
+        // lane whose path has ended takes the next one of the share, so the waves stay full until the queue is
+        // empty, and the launch ends as long after that as its longest path.
+        uint32_t extra_queries = 0, deepest = depth0, taken = 0;
+        const uint32_t CHUNK = max(64u, min(1024u, (total / (gridDim.x * (BLOCK / 64) * 8u)) & ~63u));
+        uint32_t chunk_lo = 0, chunk_hi = 0;  // (wave-uniform) what is left of the wave's share
+        bool exhausted = false;               // (wave-uniform)
+        bool alive = false;
+        Ray<T> ray;
+        V3<T> thr;
+        uint32_t pid = 0, depth = depth0;
+        ray.o = ray.d = thr = mk((T)0.0, (T)0.0, (T)0.0);
+        ray.time = (T)0.0;
+        for (;;) {
+            while (!exhausted) {
+                const uint64_t idle = __ballot(!alive);
+                if (idle == 0) break;
+                if (chunk_lo >= chunk_hi) {
+                    uint32_t fresh = 0;
+                    if (lane == 0) fresh = atomicAdd(tail.cursor, CHUNK);
+                    fresh = (uint32_t)__shfl((int)fresh, 0);
+                    if (fresh >= total) {
+                        exhausted = true;
+                        break;
+                    }
+                    chunk_lo = fresh;
+                    chunk_hi = min(fresh + CHUNK, total);
+                }
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t avail = chunk_hi - chunk_lo;
+                if (!alive && rank < avail) {
+                    uint32_t tile;
+                    const uint32_t i = slot_of(tile_offsets, n_tiles, chunk_lo + rank, chunk_lo, &tile);
+                    ray = load_ray(qin, i);
+                    pid = qin.pid[i];
+                    thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
+                    depth = depth0;
+                    alive = true;
+                    taken++;
+                }
+                chunk_lo += min((uint32_t)__popcll(idle), avail);
+            }
+            if (__ballot(alive) == 0) break;
+            if (alive) {
+                Ray<T> nr;
+                if (depth > depth0) extra_queries++;
+                deepest = max(deepest, depth + 1);
+                alive = bounce_once(ray, thr, pid, depth, nr);
+                ray = nr;  // the scattered ray is the next bounce's query
+                depth++;
+            }
+        }
+        // rays and depth statistics of the bounces that were not launches
         for (int off = 32; off > 0; off >>= 1) {
             extra_queries += __shfl_xor(extra_queries, off);
+            taken += __shfl_xor(taken, off);
             deepest = max(deepest, (uint32_t)__shfl_xor(deepest, off));
         }
         if (lane == 0) {
             if (extra_queries) atomicAdd(tail.ray_total, (unsigned long long)extra_queries);
+            if (taken) atomicAdd(tail.ray_total + 1, (unsigned long long)taken);
             atomicMax(tail.deepest, deepest);
         }
     }
@@ -1818,6 +1887,7 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate(const T* sample_rgb, uint3
     accum[e] = acc;
 }
 
+#if RT_PART_HAS(2)
 __global__ void __launch_bounds__(BLOCK) k_quantize(const double* accum, uint64_t n, uint32_t spp_total, uint8_t* rgb8) {
     uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (e >= n) return;
@@ -1828,6 +1898,7 @@ __global__ void __launch_bounds__(BLOCK) k_quantize(const double* accum, uint64_
     double f = floor(255.0 * c);
     rgb8[e] = f != f ? 0 : f <= 0.0 ? 0 : f >= 255.0 ? 255 : (uint8_t)f;  // `as u8`: saturating, NaN -> 0
 }
+#endif
 
 // rt_trace plumbing: AoS f64 host layout <-> SoA queues.
 template <typename T>
@@ -2000,16 +2071,49 @@ template <typename T>
 void Launch<T>::store_rays(DQueue<T> q, uint32_t n, double* rays9, hipStream_t st) {
     hipLaunchKernelGGL(k_store_rays<T>, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, q, n, rays9);
 }
+#if RT_PART_HAS(2)
 void launch_scan_tiles(const uint32_t* tile_counts, uint32_t n_tiles, uint32_t* tile_offsets, uint32_t* counts_to_zero,
-                       uint32_t* total_out, unsigned long long* ray_total, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, st, tile_counts, n_tiles, tile_offsets, counts_to_zero, total_out, ray_total);
+                       uint32_t* total_out, unsigned long long* ray_total, uint32_t* host_total, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, st, tile_counts, n_tiles, tile_offsets, counts_to_zero, total_out, ray_total, host_total);
 }
 void launch_quantize(const double* accum, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb8, hipStream_t st) {
     uint64_t n = n_pixels * 3;
     hipLaunchKernelGGL(k_quantize, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, accum, n, spp_total, rgb8);
 }
+#endif
 
-template struct Launch<double>;
-template struct Launch<float>;
+// Explicit instantiations, one group per translation unit (RT_PART, see the top of the file).
+#define RT_INST_EXTEND(T)                                                                                                        \
+    template void Launch<T>::extend(const DScene<T>&, const DSmallScene&, const DBatch&, DQueue<T>, DHits<T>, const T*, const T*, \
+                                    uint32_t, const uint32_t*, uint32_t, int, int, uint32_t*, int, hipStream_t);
+#define RT_INST_BOUNCE(T)                                                                                                     \
+    template void Launch<T>::bounce(const DScene<T>&, const DSmallScene&, const DBatch&, DQueue<T>, DQueue<T>, T*, uint32_t, \
+                                    uint32_t, const uint32_t*, uint32_t*, uint32_t, int, int, const DTail*, hipStream_t);
+#define RT_INST_REST(T)                                                                                                          \
+    template void Launch<T>::raygen(const DScene<T>&, const DBatch&, DQueue<T>, uint32_t, uint32_t*, hipStream_t);                \
+    template void Launch<T>::shade(const DScene<T>&, const DBatch&, DQueue<T>, DHits<T>, DQueue<T>, T*, uint32_t, uint32_t,       \
+                                   const uint32_t*, uint32_t*, uint32_t, int, hipStream_t);                                      \
+    template void Launch<T>::accumulate(const T*, uint32_t, uint32_t, double*, hipStream_t);                                     \
+    template void Launch<T>::load_rays(const double*, uint32_t, DQueue<T>, T*, T*, uint32_t*, hipStream_t);                      \
+    template void Launch<T>::store_hits(DQueue<T>, DHits<T>, uint32_t, void*, hipStream_t);                                      \
+    template void Launch<T>::store_rays(DQueue<T>, uint32_t, double*, hipStream_t);
+#if RT_PART_HAS(0)
+RT_INST_EXTEND(double)
+#endif
+#if RT_PART_HAS(1)
+RT_INST_BOUNCE(double)
+#endif
+#if RT_PART_HAS(2)
+RT_INST_REST(double)
+#endif
+#if RT_PART_HAS(3)
+RT_INST_EXTEND(float)
+#endif
+#if RT_PART_HAS(4)
+RT_INST_BOUNCE(float)
+#endif
+#if RT_PART_HAS(5)
+RT_INST_REST(float)
+#endif
 
 }  // namespace rtd

@@ -204,8 +204,9 @@ struct DBatch {      // which pixels / samples the paths of a batch stand for
 // input queue through all remaining bounces (nothing is written to the output queue) and adds the
 // closest-hit queries beyond the first / the deepest bounce reached to these counters.
 struct DTail {
-    unsigned long long* ray_total;
+    unsigned long long* ray_total;  // [0] += queries beyond a path's first bounce here, [1] += paths taken
     uint32_t* deepest;
+    uint32_t* cursor;               // zeroed (k_scan_tiles): the launch hands its paths out from here
 };
 
 // Launch wrappers (kernels.hip).  `stack` selects the LDS traversal-stack depth (16/32/64).
@@ -232,9 +233,10 @@ struct Launch {
 };
 
 // Exclusive scan of per-tile counts -> tile_offsets[0..n_tiles]; zeroes counts_to_zero[0..n_tiles) if
-// non-null; *total_out = total; *ray_total += total if non-null.
+// non-null; counts[0] = total, counts[1] = counts[3] = 0 (the cursors of the next launch); *ray_total += total
+// if non-null; *host_total = total (pinned host memory, system-scope store) if non-null.
 void launch_scan_tiles(const uint32_t* tile_counts, uint32_t n_tiles, uint32_t* tile_offsets, uint32_t* counts_to_zero,
-                       uint32_t* total_out, unsigned long long* ray_total, hipStream_t st);
+                       uint32_t* counts, unsigned long long* ray_total, uint32_t* host_total, hipStream_t st);
 void launch_quantize(const double* accum, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb8, hipStream_t st);
 
 }  // namespace rtd
