@@ -257,6 +257,19 @@ int rt_render_accum_device(rt_context* ctx, uint32_t width, uint32_t height, uin
                            uint32_t s0, uint32_t n_samples, uint32_t max_bounces, uint64_t seed,
                            double* accum_dev, rt_stats* stats /* may be NULL */);
 
+/* The same call for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  It calls no hipMalloc / hipFree (nor
+ * any other allocating routine): the ray queues, hit records and per-path samples live in a static device array of
+ * the library (32 MiB per GPU, held from the moment the library is loaded on that GPU until the process ends), sized
+ * for RT_NOALLOC_MAX_PATHS = 131072 paths in flight.  Limit: width * (j1 - j0) <= 131072 pixels per call (RT_ERR_INVALID
+ * with a message otherwise); the samples are traced in batches of floor(131072 / pixels) and added in sample order,
+ * so accum is bit-identical to rt_render_accum_device's.  Every call on a GPU - from any context - uses that GPU's one
+ * array: calls that overlap on one GPU race; make them one after the other.  No statistics, no launch timing. */
+#define RT_NOALLOC_MAX_PATHS 131072u
+int rt_render_accum_device_noalloc(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0, uint32_t j1,
+                                   uint32_t s0, uint32_t n_samples, uint32_t max_bounces, uint64_t seed,
+                                   double* accum_dev);
+
 /* Replaces src/main.rs:138-142 + colour_to_raw (src/main.rs:172-177): mean over
  * spp_total, sqrt, abs / clamp [0, 0.999], floor(255 x).  Both pointers are device memory. */
 int rt_quantize_device(rt_context* ctx, const double* accum_dev, uint64_t n_pixels, uint32_t spp_total,

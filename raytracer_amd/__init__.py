@@ -25,6 +25,7 @@ __all__ = [
 # RT_MI355X_LIB overrides the library path (A/B runs of kernel variants); default: the in-tree build.
 LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt_mi355x.so")
 
+NOALLOC_MAX_PATHS = 131072  # RT_NOALLOC_MAX_PATHS
 PRECISION_F64 = 0
 PRECISION_F32 = 1
 
@@ -88,6 +89,7 @@ EXPORTS = [
     ("rt_trace", C.c_int, [_vp, _vp, C.c_size_t, _u64, _vp]),
     ("rt_primary_rays", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u64, _vp]),
     ("rt_render_accum_device", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _vp, C.POINTER(RtStats)]),
+    ("rt_render_accum_device_noalloc", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _vp]),
     ("rt_quantize_device", C.c_int, [_vp, _vp, _u64, _u32, _vp]),
     ("rt_render_rows", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _vp, _vp, C.POINTER(RtStats)]),
     # host I/O
@@ -255,6 +257,13 @@ class Renderer:
         self._check(self._lib.rt_render_accum_device(self._h, width, height, j0, j1, s0, n_samples, max_bounces, seed,
                                                      accum_ptr, C.byref(stats) if want_stats else None))
         return stats
+
+    def render_accum_device_noalloc(self, width: int, height: int, j0: int, j1: int, s0: int, n_samples: int,
+                                    max_bounces: int, seed: int, accum_ptr: int) -> None:
+        """rt_render_accum_device for callers that cannot allocate: work buffers in the library's static device array,
+        at most NOALLOC_MAX_PATHS pixels per call."""
+        self._check(self._lib.rt_render_accum_device_noalloc(self._h, width, height, j0, j1, s0, n_samples, max_bounces,
+                                                             seed, accum_ptr))
 
     def quantize_device(self, accum_ptr: int, n_pixels: int, spp_total: int, rgb8_ptr: int) -> None:
         self._check(self._lib.rt_quantize_device(self._h, accum_ptr, n_pixels, spp_total, rgb8_ptr))

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -260,7 +261,6 @@ struct OwnedWork {
 };
 
 // Paths in flight of the allocation-free entry point, and the bytes of its buffers (f64: 244 B per path).
-#define RT_NOALLOC_MAX_PATHS (1u << 17)
 #define RT_DEFAULT_LANES 2
 constexpr size_t work_bytes(size_t elem, size_t paths) {
     const size_t tiles = (paths + RT_TILE - 1) / RT_TILE;
@@ -1190,6 +1190,30 @@ struct Engine : EngineBase {
 
 }  // namespace
 
+// ---- the work area of rt_render_accum_device_noalloc: device memory that exists from the moment the library's
+// code object is loaded on a GPU until the process ends, so that the entry point never allocates.  Each GPU holds
+// its own copy at its own address: host code never uses the array's name as an address, only the pointer
+// hipGetSymbolAddress returned for that device (scratch_for_device).
+constexpr size_t RT_NOALLOC_BYTES = work_bytes(sizeof(double), RT_NOALLOC_MAX_PATHS);
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES];
+std::mutex g_scratch_mutex;
+// The address of `scratch` on device `dev`, which must be the current device.
+void* scratch_for_device(int dev) {
+    if (dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        HIP_CHECK(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[dev] = ptr;
+    }
+    return g_scratch_ptr[dev];
+}
+}  // namespace
+
 struct rt_scene {
     rt::Scene scene;
     rt::FlatScene flat;
@@ -1322,10 +1346,11 @@ int rt_create(int device_id, const rt_options* options, rt_context** out) {
         int n_lanes = options && options->lanes > 0 ? options->lanes : RT_DEFAULT_LANES;
         if (const char* e = std::getenv("RT_LANES")) n_lanes = (int)std::strtol(e, nullptr, 10);
         n_lanes = std::max(1, std::min(8, n_lanes));
+        void* fixed_base = scratch_for_device(device_id);  // (this device is current: DeviceScope above)
         if (precision == RT_PRECISION_F64)
-            ctx->engine.reset(new Engine<double>(ctx->stream, prop.multiProcessorCount, max_paths, n_lanes, nullptr, 0));
+            ctx->engine.reset(new Engine<double>(ctx->stream, prop.multiProcessorCount, max_paths, n_lanes, fixed_base, RT_NOALLOC_BYTES));
         else if (precision == RT_PRECISION_F32)
-            ctx->engine.reset(new Engine<float>(ctx->stream, prop.multiProcessorCount, max_paths, n_lanes, nullptr, 0));
+            ctx->engine.reset(new Engine<float>(ctx->stream, prop.multiProcessorCount, max_paths, n_lanes, fixed_base, RT_NOALLOC_BYTES));
         else
             throw RtError{RT_ERR_INVALID, "rt_create: unknown precision"};
         ctx->max_paths = max_paths;
@@ -1391,6 +1416,21 @@ int rt_render_accum_device(rt_context* ctx, uint32_t width, uint32_t height, uin
         if (!accum_dev && j1 > j0 && n_samples) throw RtError{RT_ERR_INVALID, "rt_render_accum_device: null accum buffer"};
         if ((uint64_t)s0 + n_samples > 0xffffffffull) throw RtError{RT_ERR_INVALID, "sample index overflow"};
         ctx->engine->render_accum(width, height, j0, j1, s0, n_samples, max_bounces, seed, accum_dev, stats, false);
+    });
+}
+
+int rt_render_accum_device_noalloc(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0, uint32_t j1, uint32_t s0,
+                                   uint32_t n_samples, uint32_t max_bounces, uint64_t seed, double* accum_dev) {
+    return guard(ctx, [&] {
+        if (width < 2 || height < 2 || j0 > j1 || j1 > height)
+            throw RtError{RT_ERR_INVALID, "rt_render_accum_device_noalloc: bad image geometry (width, height >= 2, j0 <= j1 <= height)"};
+        if (!accum_dev && j1 > j0 && n_samples) throw RtError{RT_ERR_INVALID, "rt_render_accum_device_noalloc: null accum buffer"};
+        if ((uint64_t)s0 + n_samples > 0xffffffffull) throw RtError{RT_ERR_INVALID, "sample index overflow"};
+        if ((uint64_t)width * (j1 - j0) > RT_NOALLOC_MAX_PATHS)
+            throw RtError{RT_ERR_INVALID, "rt_render_accum_device_noalloc: rows [j0, j1) hold " + std::to_string((uint64_t)width * (j1 - j0)) +
+                                              " pixels, more than the " + std::to_string(RT_NOALLOC_MAX_PATHS) +
+                                              " paths the library's static work area holds; render fewer rows per call"};
+        ctx->engine->render_accum(width, height, j0, j1, s0, n_samples, max_bounces, seed, accum_dev, nullptr, true);
     });
 }
 
