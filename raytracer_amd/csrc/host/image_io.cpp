@@ -147,11 +147,12 @@ ImageRGB8 decode_jpeg_baseline(const uint8_t* d, size_t size) {
     for (;;) {
         if (i + 4 > size) throw SceneError("JPEG: truncated file");
         if (d[i] != 0xFF) throw SceneError("JPEG: expected a marker");
-        while (i < size && d[i + 1] == 0xFF) i++;
+        while (i + 2 < size && d[i + 1] == 0xFF) i++;  // fill bytes before a marker
         int m = d[i + 1];
         i += 2;
         if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
         if (m == 0xD9) throw SceneError("JPEG: no image data");
+        if (i + 2 > size) throw SceneError("JPEG: truncated file");
         size_t len = be16(d + i);
         if (len < 2 || i + len > size) throw SceneError("JPEG: bad segment length");
         const uint8_t* seg = d + i + 2;
@@ -161,7 +162,8 @@ ImageRGB8 decode_jpeg_baseline(const uint8_t* d, size_t size) {
             while (k < seglen) {
                 int pq = seg[k] >> 4, tq = seg[k] & 15;
                 k++;
-                if (tq > 3) throw SceneError("JPEG: bad quantisation table id");
+                if (tq > 3 || pq > 1) throw SceneError("JPEG: bad quantisation table id");
+                if (k + (pq ? 128u : 64u) > seglen) throw SceneError("JPEG: truncated quantisation table");
                 for (int z = 0; z < 64; z++) {
                     if (pq) {
                         qt[tq][z] = be16(seg + k);
@@ -184,12 +186,14 @@ ImageRGB8 decode_jpeg_baseline(const uint8_t* d, size_t size) {
                 k += 17 + (size_t)nsym;
             }
         } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1 (Huffman, sequential)
+            if (seglen < 6) throw SceneError("JPEG: truncated frame header");
             if (seg[0] != 8) throw SceneError("JPEG: only 8-bit precision is supported");
             height = be16(seg + 1);
             width = be16(seg + 3);
             int n = seg[5];
             if ((n != 1 && n != 3) || width == 0 || height == 0)
                 throw SceneError("JPEG: unsupported component count or size");
+            if (seglen < 6 + 3 * (size_t)n) throw SceneError("JPEG: truncated frame header");
             comps.resize((size_t)n);
             for (int c = 0; c < n; c++) {
                 comps[c].id = seg[6 + 3 * c];
@@ -204,17 +208,21 @@ ImageRGB8 decode_jpeg_baseline(const uint8_t* d, size_t size) {
         } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
             throw SceneError("JPEG: only baseline (SOF0/SOF1) files are supported");
         } else if (m == 0xDD) {
+            if (seglen < 2) throw SceneError("JPEG: truncated restart interval");
             restart_interval = be16(seg);
         } else if (m == 0xEE && seglen >= 12 && std::memcmp(seg, "Adobe", 5) == 0) {
             adobe = true;
             adobe_transform = seg[11];
         } else if (m == 0xDA) {  // SOS
             if (comps.empty()) throw SceneError("JPEG: scan before frame header");
+            if (seglen < 1) throw SceneError("JPEG: truncated scan header");
             int ns = seg[0];
             if (ns != (int)comps.size()) throw SceneError("JPEG: non-interleaved scans are not supported");
+            if (seglen < 1 + 2 * (size_t)ns) throw SceneError("JPEG: truncated scan header");
             for (int s = 0; s < ns; s++) {
                 int cid = seg[1 + 2 * s];
                 int tab = seg[2 + 2 * s];
+                if ((tab >> 4) > 3 || (tab & 15) > 3) throw SceneError("JPEG: bad Huffman table id in scan header");
                 bool found = false;
                 for (auto& c : comps)
                     if (c.id == cid) {
@@ -259,6 +267,7 @@ ImageRGB8 decode_jpeg_baseline(const uint8_t* d, size_t size) {
                     for (int bx = 0; bx < c.h; bx++) {
                         double coef[64] = {};
                         int t = decode_symbol(br, hdc[c.td]);
+                        if (t > 16) throw SceneError("JPEG: bad DC coefficient size");
                         int diff = t ? extend(br.get(t), t) : 0;
                         c.dc_pred += diff;
                         coef[0] = (double)c.dc_pred * qt[c.tq][0];

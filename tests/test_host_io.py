@@ -274,3 +274,73 @@ def test_cli_scene_and_part_file_errors_leave_no_part_file(in_tmp):
     r = _cli(scene, "out.png", "-w", "32", "-r", "bad.PART")
     assert r.returncode == 1 and "Image dimensions expected to be 32x32" in r.stderr
     assert sorted(os.listdir(".")) == ["bad.PART"]
+
+
+def _texture_scene(name):
+    return """{
+      camera: {lookFrom: [0,0,-5], lookAt: [0,0,0], directionUp: [0,1,0], fieldOfView: 40, aspectRatio: [1,1],
+               aperture: 0, distanceToFocus: 5, startTime: 0, endTime: 1},
+      background: {type: "plainColour", colour: [0,0,0]},
+      textures: {t: {type: "imageTexture", filename: "%s"}},
+      materials: {m: {type: "lambertian", texture: "t"}},
+      objects: {s: {type: "sphere", centre: [0,0,0], radius: 1, material: "m"}},
+      world: ["s"],
+    }""" % name
+
+
+def test_malformed_jpeg_textures_are_errors_not_faults(in_tmp):
+    # A texture file is untrusted input: truncated or garbage segments must come back as RT_ERR_SCENE (or decode to
+    # something), never read out of bounds.  Run under the library as built; the checks are in image_io.cpp.
+    img = _test_picture(24, 40)
+    rt.save_image("good.jpg", img)
+    raw = bytearray(open("good.jpg", "rb").read())
+
+    def load(data):
+        open("bad.jpg", "wb").write(bytes(data))
+        return rt.Scene.from_text(_texture_scene("bad.jpg"), ".")
+
+    def segments(data):
+        i, out = 2, {}
+        while i + 4 <= len(data) and data[i] == 0xFF:
+            m, ln = data[i + 1], (data[i + 2] << 8) | data[i + 3]
+            out.setdefault(m, i)
+            if m == 0xDA:
+                break
+            i += 2 + ln
+        return out
+
+    seg = segments(raw)
+    assert {0xDB, 0xC0, 0xC4, 0xDA} <= set(seg)
+    # every truncation of the headers
+    for cut in range(2, seg[0xDA] + 14):  # (beyond the scan header the missing entropy data reads as zeros)
+        with pytest.raises(rt.RtError):
+            load(raw[:cut])
+    # SOS names Huffman tables 15 / 15 (used to index hdc[4] / hac[4] out of bounds)
+    bad = bytearray(raw)
+    bad[seg[0xDA] + 6] = 0xFF
+    with pytest.raises(rt.RtError, match="Huffman table id"):
+        load(bad)
+    # DQT whose length says one byte of table
+    bad = bytearray(raw)
+    q = seg[0xDB]
+    bad[q + 2:q + 4] = b"\x00\x04"
+    with pytest.raises(rt.RtError):
+        load(bad[:q + 6] + raw[q + 2 + ((raw[q + 2] << 8) | raw[q + 3]):])
+    # SOF / SOS / DRI shorter than their fields
+    for m, ln in ((0xC0, 4), (0xC0, 9), (0xDA, 2), (0xDA, 4)):
+        bad = bytearray(raw)
+        at = seg[m]
+        old = (raw[at + 2] << 8) | raw[at + 3]
+        with pytest.raises(rt.RtError):
+            load(bad[:at + 2] + bytes([0, ln]) + raw[at + 4:at + 2 + ln] + raw[at + 2 + old:])
+    with pytest.raises(rt.RtError):
+        load(raw[:seg[0xDA]] + b"\xff\xdd\x00\x02" + raw[seg[0xDA]:])
+    # random corruption of single header bytes: an error or a picture, never a crash
+    rng = np.random.default_rng(11)
+    for _ in range(300):
+        bad = bytearray(raw)
+        bad[int(rng.integers(2, seg[0xDA] + 14))] = int(rng.integers(0, 256))
+        try:
+            load(bad)
+        except rt.RtError:
+            pass
