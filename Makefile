@@ -33,9 +33,13 @@ $(OBJDIR)/capi.o: raytracer_amd/csrc/capi.cpp raytracer_amd/csrc/tree_layout.hpp
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/librt_mi355x.so: $(HOST_OBJS) $(KERNEL_OBJS) $(OBJDIR)/capi.o
+$(OBJDIR)/multi.o: raytracer_amd/csrc/multi.cpp raytracer_amd/csrc/device/rt_device.h include/rt_mi355x.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/librt_mi355x.so: $(HOST_OBJS) $(KERNEL_OBJS) $(OBJDIR)/capi.o $(OBJDIR)/multi.o
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lz
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lz -ldl -lpthread
 
 # Command-line host: the reference's `raytracer` binary over the C ABI.
 bin/raytracer: $(HOSTDIR)/cli_main.cpp $(OBJDIR)/part_file.o $(OBJDIR)/progress.o $(OBJDIR)/image_out.o $(LIBDIR)/librt_mi355x.so

@@ -282,6 +282,39 @@ int rt_render_rows(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0
                    uint32_t spp, uint32_t max_bounces, uint64_t seed, uint8_t* rgb8, double* sum_rgb,
                    rt_stats* stats /* may be NULL */);
 
+/* ------------------------------------------------------------------ several GPUs, one process
+ * Replaces the rayon row loop of src/main.rs:117-154 (`into_par_iter` over rows, all cores of one machine) at node
+ * scale: the GPUs of device_ids share every band of rows by SAMPLE index (device g traces rt_split_samples(spp, n, g)
+ * of every pixel; the scene is replicated), the per-pixel f64 sums are combined on device_ids[0] by one RCCL
+ * ncclReduce(sum, f64) per band over xGMI, and that device quantises.  A band's reduce and quantisation run while the
+ * next band is traced.  With spp < n the ROWS of a band are split instead and nothing is reduced.  The image equals
+ * rt_render_rows' up to the order of the n f64 additions per sum (random streams are keyed by pixel and sample index).
+ * One host thread per device is started inside the calls; the rt_multi is used by one caller thread at a time.
+ * RCCL is loaded on demand (dlopen); RT_REDUCE=p2p in the environment, or a device list that names a GPU twice (one-GPU
+ * rehearsals), sums by peer copies to device_ids[0] and an add kernel instead. */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const int* device_ids, int n_devices, const rt_options* options /* may be NULL */, rt_multi** out);
+void rt_multi_destroy(rt_multi* m);
+int rt_multi_device_count(const rt_multi* m);
+const char* rt_multi_last_error(const rt_multi* m /* NULL: the last failed rt_multi_create on this thread */);
+int rt_multi_upload_scene(rt_multi* m, const rt_scene_desc* scene);
+int rt_multi_set_launch_timing(rt_multi* m, int on);
+/* rt_render_rows over all devices.  band_rows: rows per reduce (0 = as many as fit the path budget, i.e. usually the
+ * whole call in one band); rgb8 / sum_rgb / stats as in rt_render_rows (stats: sums over the devices, ms_total = the
+ * slowest device's). */
+int rt_multi_render_rows(rt_multi* m, uint32_t width, uint32_t height, uint32_t j0, uint32_t j1, uint32_t spp,
+                         uint32_t max_bounces, uint64_t seed, uint32_t band_rows, uint8_t* rgb8, double* sum_rgb,
+                         rt_stats* stats /* may be NULL */);
+/* The same with a call-back for finished rows: on_band(user, b0, b1) is called on the caller's thread, in band order, when
+ * rows [b0, b1) are final in rgb8 / sum_rgb (the hand-over of `(j, row)` to monitor_progress, src/main.rs:144, 223-238). */
+typedef void (*rt_band_callback)(void* user, uint32_t b0, uint32_t b1);
+int rt_multi_render_rows_cb(rt_multi* m, uint32_t width, uint32_t height, uint32_t j0, uint32_t j1, uint32_t spp,
+                            uint32_t max_bounces, uint64_t seed, uint32_t band_rows, uint8_t* rgb8, double* sum_rgb,
+                            rt_stats* stats, rt_band_callback on_band, void* user);
+/* The partition rule: part `part` of `parts` gets `count` consecutive items from `begin`; the ranges cover
+ * [first, first + total) exactly once and the first total % parts parts take one extra item. */
+void rt_split_samples(uint32_t total, uint32_t parts, uint32_t part, uint32_t first, uint32_t* begin, uint32_t* count);
+
 /* ------------------------------------------------------------------ host I/O (no GPU)
  * The file formats either side of the row loop, for hosts that keep the reference's
  * command-line behaviour (bin/raytracer does).  Errors: rt_last_global_error(). */

@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 __all__ = [
-    "load_library", "Scene", "Renderer", "RtError", "RtStats", "RtUploadStats", "RAY_DTYPE", "HIT_DTYPE",
+    "load_library", "Scene", "Renderer", "MultiRenderer", "split_samples_c", "RtError", "RtStats", "RtUploadStats", "RAY_DTYPE", "HIT_DTYPE",
     "PRECISION_F64", "PRECISION_F32", "LIB_PATH", "PartFile", "read_part_file", "save_image", "ProgressBar",
 ]
 
@@ -92,6 +92,16 @@ EXPORTS = [
     ("rt_render_accum_device_noalloc", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _vp]),
     ("rt_quantize_device", C.c_int, [_vp, _vp, _u64, _u32, _vp]),
     ("rt_render_rows", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _vp, _vp, C.POINTER(RtStats)]),
+    # several GPUs, one process
+    ("rt_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(RtOptions), C.POINTER(_vp)]),
+    ("rt_multi_destroy", None, [_vp]),
+    ("rt_multi_device_count", C.c_int, [_vp]),
+    ("rt_multi_last_error", C.c_char_p, [_vp]),
+    ("rt_multi_upload_scene", C.c_int, [_vp, _vp]),
+    ("rt_multi_set_launch_timing", C.c_int, [_vp, C.c_int]),
+    ("rt_multi_render_rows", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _u32, _vp, _vp, C.POINTER(RtStats)]),
+    ("rt_multi_render_rows_cb", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _u32, _vp, _vp, C.POINTER(RtStats), _vp, _vp]),
+    ("rt_split_samples", None, [_u32, _u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     # host I/O
     ("rt_part_file_create", C.c_int, [C.c_char_p, _u32, _u32, C.POINTER(_vp)]),
     ("rt_part_file_path", C.c_char_p, [_vp]),
@@ -125,6 +135,10 @@ def _share_torch_hip_runtime() -> None:
     path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
     if os.path.exists(path):
         C.CDLL(path, mode=C.RTLD_GLOBAL)
+    # the same for RCCL, which rt_multi_create loads on demand (dlopen): name torch's copy, do not load it here
+    rccl = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("RT_RCCL_LIB", rccl)
 
 
 def load_library() -> C.CDLL:
@@ -278,6 +292,64 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+class MultiRenderer:
+    """One image over several GPUs from this process (rt_multi): sample split, one RCCL reduce per band."""
+
+    def __init__(self, devices, precision: int = PRECISION_F64, max_paths: int = 0, lanes: int = 0):
+        lib = load_library()
+        opts = RtOptions(precision, lanes, max_paths)
+        ids = (C.c_int * len(devices))(*devices)
+        out = _vp()
+        rc = lib.rt_multi_create(ids, len(devices), C.byref(opts), C.byref(out))
+        if rc != 0:
+            raise RtError(rc, lib.rt_multi_last_error(None).decode("utf-8", "replace"))
+        self._h = out.value
+        self._lib = lib
+        self.devices = list(devices)
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise RtError(rc, self._lib.rt_multi_last_error(self._h).decode("utf-8", "replace"))
+
+    def upload(self, scene: Scene) -> None:
+        self._check(self._lib.rt_multi_upload_scene(self._h, scene.desc_ptr))
+
+    def render_rows(self, width: int, height: int, j0: int, j1: int, spp: int, max_bounces: int, seed: int = 0,
+                    band_rows: int = 0, want_sums: bool = True, on_band=None) -> Tuple[np.ndarray, Optional[np.ndarray], RtStats]:
+        """on_band(b0, b1): called in band order when rows [b0, b1) are final."""
+        rows = max(j1 - j0, 0)
+        rgb8 = np.zeros((rows, width, 3), dtype=np.uint8)
+        sums = np.zeros((rows, width, 3), dtype=np.float64) if want_sums else None
+        stats = RtStats()
+        if on_band is None:
+            self._check(self._lib.rt_multi_render_rows(self._h, width, height, j0, j1, spp, max_bounces, seed, band_rows,
+                                                       rgb8.ctypes.data, sums.ctypes.data if want_sums else None, C.byref(stats)))
+        else:
+            cb = C.CFUNCTYPE(None, _vp, _u32, _u32)(lambda user, b0, b1: on_band(int(b0), int(b1)))
+            self._check(self._lib.rt_multi_render_rows_cb(self._h, width, height, j0, j1, spp, max_bounces, seed, band_rows,
+                                                          rgb8.ctypes.data, sums.ctypes.data if want_sums else None, C.byref(stats),
+                                                          C.cast(cb, _vp), None))
+        return rgb8, sums, stats
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.rt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def split_samples_c(total: int, parts: int, part: int, first: int = 0) -> Tuple[int, int]:
+    """rt_split_samples: the library's partition rule (the same as parallel.split_samples)."""
+    b, c = _u32(), _u32()
+    load_library().rt_split_samples(total, parts, part, first, C.byref(b), C.byref(c))
+    return int(b.value), int(c.value)
 
 
 def _check_global(rc: int) -> None:

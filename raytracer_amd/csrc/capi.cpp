@@ -1275,6 +1275,7 @@ static int guard(rt_context* ctx, F&& f) {
         return RT_ERR_INVALID;
     }
     int rc = guard_global([&] {
+        (void)hipGetLastError();  // an error left behind by the caller's own HIP calls is not ours to report
         DeviceScope scope(ctx->device);
         f();
     });

@@ -1128,8 +1128,8 @@ __device__ __forceinline__ uint32_t slot_of(const uint32_t* __restrict__ offsets
 
 // One block: exclusive scan of the per-tile counts of the queue that is read next; also
 // clears the counts of the queue that is written next and keeps the global totals.
-constexpr int SCAN_THREADS = 1024;
 #if RT_PART_HAS(2)
+constexpr int SCAN_THREADS = 1024;
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_tiles(const uint32_t* __restrict__ tile_counts, uint32_t n_tiles,
                                                               uint32_t* __restrict__ tile_offsets,
                                                               uint32_t* __restrict__ counts_to_zero,

@@ -5,6 +5,7 @@
 // crash-recovery file, one record per finished row.
 //
 // Differences from the reference, all deliberate:
+//  * --gpus / --devices render one image over several GPUs (rt_multi_*: samples split, one RCCL reduce per band).
 //  * --seed / --precision / --device / --band-rows / --stats are new (the reference draws from
 //    thread_rng, so its images are not reproducible; without --seed ours are not either).
 //  * the monitor thread is always joined (the reference skips the join under --quiet and can exit
@@ -59,6 +60,8 @@ const char* kHelp =
     "OPTIONS:\n"
     "        --band-rows <n>                 Rows per GPU batch (default: about 2^24 camera paths)\n"
     "        --device <n>                    GPU to render on [default: 0]\n"
+    "        --devices <a,b,..>              GPUs to share the image (samples are split, one RCCL reduce per band)\n"
+    "        --gpus <n>                      The same with GPUs 0 .. n-1\n"
     "    -m, --max-bounces <max-bounces>     Maximum number of bounces for any ray [default: 50]\n"
     "        --precision <f64|f32>           Arithmetic of the path tracer [default: f64]\n"
     "        --progress-bar-len <n>          Manually set length of progress bar\n"
@@ -83,6 +86,7 @@ struct Opt {
     std::optional<uint64_t> seed;
     int precision = RT_PRECISION_F64;
     int device = 0;
+    std::vector<int> devices;  // --gpus / --devices: more than one GPU (rt_multi_*)
     uint32_t band_rows = 0;
 };
 
@@ -160,7 +164,21 @@ Opt parse_args(int argc, char** argv) {
         else if (name == "--stats") flag(o.stats);
         else if (name == "--seed") o.seed = parse_uint("--seed <n>", value(), UINT64_MAX);
         else if (name == "--device") o.device = (int)parse_uint("--device <n>", value(), 1023);
-        else if (name == "--band-rows") o.band_rows = (uint32_t)parse_uint("--band-rows <n>", value(), UINT32_MAX);
+        else if (name == "--gpus") {
+            const int n = (int)parse_uint("--gpus <n>", value(), 64);
+            if (n < 1) usage_error("Invalid value for '--gpus <n>': at least 1");
+            o.devices.clear();
+            for (int g = 0; g < n; g++) o.devices.push_back(g);
+        } else if (name == "--devices") {
+            const std::string list = value();
+            o.devices.clear();
+            size_t at = 0;
+            while (at <= list.size()) {
+                const size_t comma = std::min(list.find(',', at), list.size());
+                o.devices.push_back((int)parse_uint("--devices <a,b,..>", list.substr(at, comma - at), 1023));
+                at = comma + 1;
+            }
+        } else if (name == "--band-rows") o.band_rows = (uint32_t)parse_uint("--band-rows <n>", value(), UINT32_MAX);
         else if (name == "--precision") {
             std::string v = value();
             if (v == "f64") o.precision = RT_PRECISION_F64;
@@ -272,16 +290,28 @@ int run(const Opt& opt) {
     rt_options options{};
     options.precision = opt.precision;
     rt_context* ctx = nullptr;
-    if (rt_create(opt.device, &options, &ctx) != RT_OK) throw Fail(rt_last_global_error());
+    rt_multi* multi = nullptr;  // several GPUs (--gpus / --devices); one GPU goes through rt_render_rows
+    const bool many = opt.devices.size() > 1;
+    if (many) {
+        if (rt_multi_create(opt.devices.data(), (int)opt.devices.size(), &options, &multi) != RT_OK) throw Fail(rt_multi_last_error(nullptr));
+    } else {
+        if (rt_create(opt.devices.empty() ? opt.device : opt.devices[0], &options, &ctx) != RT_OK) throw Fail(rt_last_global_error());
+    }
     struct CtxGuard {
         rt_context* c;
+        rt_multi* m;
         rt_scene* s;
         ~CtxGuard() {
             rt_destroy(c);
+            rt_multi_destroy(m);
             rt_scene_free(s);
         }
-    } guard{ctx, scene};
-    if (rt_upload_scene(ctx, rt_scene_get_desc(scene)) != RT_OK) throw Fail(rt_last_error(ctx));
+    } guard{ctx, multi, scene};
+    if (many) {
+        if (rt_multi_upload_scene(multi, rt_scene_get_desc(scene)) != RT_OK) throw Fail(rt_multi_last_error(multi));
+    } else if (rt_upload_scene(ctx, rt_scene_get_desc(scene)) != RT_OK) {
+        throw Fail(rt_last_error(ctx));
+    }
 
     // Nothing has been written so far: a bad scene, part file or GPU leaves no new .PART behind.
     RowChannel channel;
@@ -324,11 +354,35 @@ int run(const Opt& opt) {
             continue;
         }
         uint32_t lo = hi - 1;
-        while (lo > 0 && !base[lo - 1] && hi - (lo - 1) <= band) lo--;
+        // one GPU: a band per call; several: the whole run of missing rows per call, cut into bands inside, so that a
+        // band's reduce runs under the next band's tracing (rows arrive through the call-back, band by band)
+        while (lo > 0 && !base[lo - 1] && (many || hi - (lo - 1) <= band)) lo--;
         band_rgb.resize((size_t)(hi - lo) * row_bytes);
         rt_stats st{};
-        if (rt_render_rows(ctx, width, height, lo, hi, opt.ray_samples, opt.max_bounces, seed, band_rgb.data(), nullptr, &st) != RT_OK)
+        if (many) {
+            // The library's bands run upwards from `lo`; the reference hands rows over from the top down.  The bar and
+            // the part file only need every row once (records carry their row number), so they go in band order.
+            struct Sink {
+                RowChannel* channel;
+                const std::vector<uint8_t>* rgb;
+                uint32_t lo;
+                size_t row_bytes;
+                decltype(place)* put;
+            } sink{&channel, &band_rgb, lo, row_bytes, &place};
+            auto on_band = [](void* user, uint32_t b0, uint32_t b1) {
+                Sink& k = *(Sink*)user;
+                for (uint32_t j = b1; j-- > b0;) {
+                    const uint8_t* row = &(*k.rgb)[(size_t)(j - k.lo) * k.row_bytes];
+                    (*k.put)(j, row);
+                    k.channel->send(j, std::vector<uint8_t>(row, row + k.row_bytes));
+                }
+            };
+            if (rt_multi_render_rows_cb(multi, width, height, lo, hi, opt.ray_samples, opt.max_bounces, seed, band, band_rgb.data(), nullptr,
+                                        &st, on_band, &sink) != RT_OK)
+                throw Fail(rt_multi_last_error(multi));
+        } else if (rt_render_rows(ctx, width, height, lo, hi, opt.ray_samples, opt.max_bounces, seed, band_rgb.data(), nullptr, &st) != RT_OK) {
             throw Fail(rt_last_error(ctx));
+        }
         total.rays += st.rays;
         total.paths += st.paths;
         total.ms_total += st.ms_total;
@@ -336,7 +390,7 @@ int run(const Opt& opt) {
         total.ms_shade += st.ms_shade;
         total.ms_tail += st.ms_tail;
         total.batches += st.batches;
-        for (uint32_t j = hi; j-- > lo;) {
+        for (uint32_t j = hi; !many && j-- > lo;) {
             const uint8_t* row = &band_rgb[(size_t)(j - lo) * row_bytes];
             place(j, row);
             channel.send(j, std::vector<uint8_t>(row, row + row_bytes));

@@ -42,6 +42,14 @@ def reduce_to_root(accum, dist=None, root: int = 0):
     return accum
 
 
+def reduce_to_root_async(accum, dist=None, root: int = 0):
+    """The same as an asynchronous collective: returns a handle whose wait() completes the sum (None for one rank), so
+    that the caller can trace the next band while this band's partial sums cross xGMI."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.reduce(accum, dst=root, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
 def render_distributed(render_range: Callable[[int, int], "object"], total_samples: int, rank: int,
                        world_size: int, dist=None, first_sample: int = 0):
     """render_range(s0, n) -> tensor of per-pixel radiance SUMS over samples [s0, s0+n).

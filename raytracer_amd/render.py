@@ -177,7 +177,10 @@ def render_image(engine, rt, *, width: int, spp: int, max_bounces: int, seed: in
         raise err if err is not None else RuntimeError("rank 0 could not read the part file")
 
     bands = plan_bands(height, present, band_rows if band_rows > 0 else default_band_rows(width, spp, world))
-    s0, n = parallel.split_samples(spp, world, rank)
+    # Fewer samples than ranks: the ROWS of a band are split instead (parallel.split_rows) - every rank traces all the
+    # samples of its rows into a zeroed band buffer, so the same reduce assembles the band and no sum is reordered.
+    tile_split = world > 1 and spp < world
+    s0, n = (0, spp) if tile_split else parallel.split_samples(spp, world, rank)
 
     pixels = monitor = None
     if rank == 0:
@@ -190,22 +193,68 @@ def render_image(engine, rt, *, width: int, spp: int, max_bounces: int, seed: in
         pixels[height - 1 - j] = row
         monitor.rows.put((j, row))
 
+    def agree(error: Optional[BaseException]) -> None:
+        """Every rank learns whether any rank failed BEFORE the next collective: a rank that left the loop alone would
+        leave its peers waiting in the reduce until the RCCL timeout."""
+        failed = 1 if error is not None else 0
+        if dist is not None and world > 1:
+            import torch
+
+            flag = engine.tensor([failed], torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = int(flag.cpu().numpy()[0])
+        if error is not None:
+            raise error
+        if failed:
+            raise RuntimeError("another rank failed while rendering; see its message")
+
+    def trace(lo: int, band_hi: int):
+        if not tile_split:
+            return engine.render_band(width, height, lo, band_hi, s0, n, max_bounces, seed)
+        r0, r1 = parallel.split_rows(band_hi - lo, world, rank)
+        accum = engine.render_band(width, height, lo, band_hi, 0, 0, max_bounces, seed)  # zeros
+        if r1 > r0:
+            part = engine.render_band(width, height, lo + r0, lo + r1, 0, spp, max_bounces, seed)
+            accum[r0 * width * 3:r1 * width * 3] = part
+        return accum
+
+    # A band's reduce runs while the next band is traced (asynchronous collective, one band in flight); the rows are
+    # handed to the monitor in descending j all the same: what follows a band waits until that band is finished.
+    todo: List = []  # what rank 0 still has to emit, in order: ("rows", [j...]) or ("band", lo, hi, accum, work)
+
+    def flush(keep_last_band: bool) -> None:
+        while todo:
+            item = todo[0]
+            if item[0] == "band":
+                if keep_last_band and len([t for t in todo if t[0] == "band"]) == 1:
+                    return
+                _, lo, band_hi, accum, work = item
+                if work is not None:
+                    work.wait()
+                if rank == 0:
+                    rgb = engine.quantize(accum, (band_hi - lo) * width, spp).reshape(band_hi - lo, width, 3)
+                    for j in range(band_hi - 1, lo - 1, -1):
+                        emit(j, rgb[j - lo])
+            elif rank == 0:
+                for j in item[1]:
+                    emit(j, base[j])
+            todo.pop(0)
+
     try:
         hi = height
         for lo, band_hi in bands:
-            if rank == 0:
-                for j in range(hi - 1, band_hi - 1, -1):  # recovered rows above this band
-                    emit(j, base[j])
-            accum = engine.render_band(width, height, lo, band_hi, s0, n, max_bounces, seed)
-            parallel.reduce_to_root(accum, dist)
-            if rank == 0:
-                rgb = engine.quantize(accum, (band_hi - lo) * width, spp).reshape(band_hi - lo, width, 3)
-                for j in range(band_hi - 1, lo - 1, -1):
-                    emit(j, rgb[j - lo])
+            todo.append(("rows", list(range(hi - 1, band_hi - 1, -1))))  # recovered rows above this band
+            error = accum = None
+            try:
+                accum = trace(lo, band_hi)
+            except BaseException as e:  # noqa: BLE001 - raised again by agree(), on every rank
+                error = e
+            agree(error)
+            todo.append(("band", lo, band_hi, accum, parallel.reduce_to_root_async(accum, dist)))
+            flush(keep_last_band=True)
             hi = lo
-        if rank == 0:
-            for j in range(hi - 1, -1, -1):
-                emit(j, base[j])
+        todo.append(("rows", list(range(hi - 1, -1, -1))))
+        flush(keep_last_band=False)
     except BaseException:
         if monitor is not None:
             monitor.rows.put(None)

@@ -155,3 +155,49 @@ def test_plan_bands():
     assert render.default_band_rows(600, 100, 1) == (1 << 24) // 60000
     assert render.default_band_rows(600, 100, 8) == (1 << 24) // (600 * 13)
     assert render.default_band_rows(3840, 10 ** 9, 1) == 1
+
+
+class _FailingEngine(_OracleEngine):
+    """Fails on one rank in the second band it is asked for."""
+
+    def __init__(self, orc, bounces, fail):
+        super().__init__(orc, bounces)
+        self.fail = fail
+        self.calls = 0
+
+    def render_band(self, *args):
+        self.calls += 1
+        if self.fail and self.calls == 2:
+            raise RuntimeError("injected failure on this rank")
+        return super().render_band(*args)
+
+
+def _failing_worker(rank, world, port, workdir):
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    import raytracer_amd as rt
+    from oracle import binding as orc
+    from raytracer_amd import render
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.chdir(workdir)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with pytest.raises(RuntimeError) as e:
+            render.render_image(_FailingEngine(orc, 4, fail=(rank == 1)), rt, width=16, spp=4, max_bounces=4, seed=1,
+                                output_file="fail.ppm", rank=rank, world=world, dist=dist, band_rows=4, quiet=True)
+        assert ("injected failure" in str(e.value)) == (rank == 1)
+        assert ("another rank failed" in str(e.value)) == (rank == 0)
+        dist.barrier()  # both ranks are still in step: nobody is stuck in a reduce
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_stops_every_rank_before_the_next_collective(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert not os.path.exists(tmp_path / "fail.ppm")
+    assert [f for f in os.listdir(tmp_path) if f.endswith(".PART")]  # kept for --recover-from

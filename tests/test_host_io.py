@@ -344,3 +344,30 @@ def test_malformed_jpeg_textures_are_errors_not_faults(in_tmp):
             load(bad)
         except rt.RtError:
             pass
+
+
+def test_partition_rule_of_the_library_matches_the_python_one():
+    # rt_split_samples (several GPUs behind the C ABI) and parallel.split_samples (one process per GPU) must agree
+    from raytracer_amd.parallel import split_samples
+
+    for total in [0, 1, 7, 8, 13, 100, 1000]:
+        for parts in [1, 2, 3, 4, 8]:
+            covered = []
+            for part in range(parts):
+                got = rt.split_samples_c(total, parts, part, first=5)
+                assert got == split_samples(total, parts, part, first_sample=5)
+                covered += list(range(got[0], got[0] + got[1]))
+            assert covered == list(range(5, 5 + total))
+    assert rt.split_samples_c(10, 0, 0) == (0, 0) and rt.split_samples_c(10, 2, 2) == (0, 0)
+
+
+def test_multi_create_without_a_gpu_is_an_error_code():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    with pytest.raises(rt.RtError) as e:
+        rt.MultiRenderer([0, 1])
+    assert e.value.code == -2
+    r = subprocess.run([CLI, "--help"], capture_output=True)
+    assert b"--gpus <n>" in r.stdout and b"--devices <a,b,..>" in r.stdout
