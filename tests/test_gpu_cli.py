@@ -41,7 +41,7 @@ def test_cli_image_is_the_library_render_and_the_oracle_render(tmp_path, gpu_sce
     rgb8, _, stats = ren.render_rows(W, H, 0, H, SPP, MB, seed=5)
     assert np.array_equal(img, rgb8[::-1])  # the file has the top row (j = H-1) first
     o8, _, _ = oracle_scenes("cornell").render(W, H, 0, H, SPP, MB, seed=5, threads=8)
-    assert (img == o8[::-1]).mean() >= 0.99
+    assert (img == o8[::-1]).mean() >= 0.9995  # measured: 1.0
     err = r.stderr.decode()
     assert "Completed in 0:0" in err and "Rendering: [" in err and f"{W * H * SPP} paths" in err
     assert os.listdir(tmp_path) == ["out.ppm"]  # the part file is removed after a complete render

@@ -180,3 +180,200 @@ def test_split_samples():
                 assert a + n == b
             assert max(n for _, n in ranges) - min(n for _, n in ranges) <= 1
     assert [split_rows(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+
+
+# ---- independent check of the loader / flattener: VALUES derived by hand from examples/*.json5 and the reference's
+# construction rules (src/config.rs:247-279 rect axis rule, src/objects.rs:149-168 Block sides, :642-700 Spotlight,
+# src/transforms.rs rotation conventions, src/camera.rs:25-66).  The oracle shares the product's scene front end
+# (oracle/Makefile), so GPU-vs-oracle tests cannot see a wrong axis rule or index; these numbers can.
+class _Rect(C.Structure):
+    _fields_ = [("a0", C.c_double), ("a1", C.c_double), ("b0", C.c_double), ("b1", C.c_double), ("k", C.c_double),
+                ("axis", C.c_int32), ("facing_positive", C.c_int32), ("material", C.c_int32), ("owner", C.c_int32),
+                ("sub", C.c_int32), ("pad", C.c_int32)]
+
+
+class _Xform(C.Structure):
+    _fields_ = [("m", C.c_double * 9), ("b", C.c_double * 3)]
+
+
+class _Material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("image", C.c_int32), ("colour", C.c_double * 3), ("param", C.c_double),
+                ("odd", C.c_int32), ("even", C.c_int32)]
+
+
+class _Object(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("xform", C.c_int32), ("first", C.c_int32), ("count", C.c_int32),
+                ("world_index", C.c_int32), ("pad", C.c_int32 * 3)]
+
+
+class _Sphere(C.Structure):
+    _fields_ = [("centre", C.c_double * 3), ("radius", C.c_double), ("material", C.c_int32), ("owner", C.c_int32)]
+
+
+class _Triangle(C.Structure):
+    _fields_ = [("point", C.c_double * 3), ("vec1", C.c_double * 3), ("vec2", C.c_double * 3), ("normal", C.c_double * 3),
+                ("material", C.c_int32), ("owner", C.c_int32), ("sub", C.c_int32), ("pad", C.c_int32)]
+
+
+class _Image(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("texel_offset", C.c_uint64)]
+
+
+class _Camera(C.Structure):
+    _fields_ = [(n, C.c_double * 3) for n in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v")] + \
+               [("lens_radius", C.c_double), ("start_time", C.c_double), ("end_time", C.c_double)]
+
+
+class _Sky(C.Structure):
+    _fields_ = [("gradient", C.c_int32), ("pad", C.c_int32), ("colour", C.c_double * 3), ("unit_dir", C.c_double * 3),
+                ("colour0", C.c_double * 3), ("colour1", C.c_double * 3)]
+
+
+_ARRAYS = [("nodes", None), ("objects", _Object), ("xforms", _Xform), ("spheres", _Sphere), ("moving_spheres", None),
+           ("rects", _Rect), ("triangles", _Triangle), ("planes", None), ("media", None), ("materials", _Material),
+           ("images", _Image), ("texels", C.c_uint8), ("top_list", C.c_int32)]
+
+
+def _desc(sc):
+    """rt_scene_desc as {name: ctypes array}, camera and sky (layout: 13 (pointer, count) pairs, 2 int32, camera, sky)."""
+    raw = (C.c_uint64 * 26).from_address(sc.desc_ptr)
+    out = {}
+    for i, (name, typ) in enumerate(_ARRAYS):
+        if typ is not None:
+            out[name] = (typ * int(raw[2 * i + 1])).from_address(raw[2 * i]) if raw[2 * i + 1] else []
+    base = sc.desc_ptr + 16 * len(_ARRAYS) + 8
+    out["camera"] = _Camera.from_address(base)
+    out["sky"] = _Sky.from_address(base + C.sizeof(_Camera))
+    return out
+
+
+def _one(items, **want):
+    hits = [x for x in items if all(getattr(x, k) == v for k, v in want.items())]
+    assert len(hits) == 1, (want, len(hits))
+    return hits[0]
+
+
+def test_cornell_flattens_to_the_values_written_by_hand(rt):
+    sc = rt.Scene.load(scene_path("cornell"), ROOT)  # (kept alive: the arrays below are views of its memory)
+    d = _desc(sc)
+    mats = d["materials"]
+
+    def material(i):
+        return mats[i].type, mats[i].image, tuple(mats[i].colour)
+
+    LAMB, LIGHT = 0, 3
+    # the six walls: the rect's fixed axis is the coordinate both corners share, tested x, then y, then z (src/config.rs:247-279);
+    # rt_rect.axis 0 = YZRect (a = y, b = z), 1 = XZRect (a = x, b = z), 2 = XYRect (a = x, b = y)
+    left = _one(d["rects"], axis=0, k=555.0, facing_positive=0)
+    assert (left.a0, left.a1, left.b0, left.b1) == (0.0, 555.0, 0.0, 555.0) and material(left.material) == (LAMB, -1, (0.12, 0.45, 0.15))
+    right = _one(d["rects"], axis=0, k=0.0, facing_positive=1, a1=555.0)
+    assert (right.a0, right.b0, right.b1) == (0.0, 0.0, 555.0) and material(right.material) == (LAMB, -1, (0.65, 0.05, 0.05))
+    light = _one(d["rects"], axis=1, k=554.0)
+    assert (light.a0, light.a1, light.b0, light.b1, light.facing_positive) == (214.0, 343.0, 227.0, 332.0, 0)
+    assert material(light.material) == (LIGHT, -1, (15.0, 15.0, 15.0))
+    floor = _one(d["rects"], axis=1, k=0.0, a1=555.0)
+    assert (floor.a0, floor.b0, floor.b1, floor.facing_positive) == (0.0, 0.0, 555.0, 1) and material(floor.material) == (LAMB, -1, (0.73, 0.73, 0.73))
+    ceiling = _one(d["rects"], axis=1, k=555.0)
+    assert (ceiling.a0, ceiling.a1, ceiling.b0, ceiling.b1, ceiling.facing_positive) == (0.0, 555.0, 0.0, 555.0, 0)
+    back = _one(d["rects"], axis=2, k=555.0)
+    assert (back.a0, back.a1, back.b0, back.b1, back.facing_positive) == (0.0, 555.0, 0.0, 555.0, 0)
+    # `world` order: leftWall, rightWall, floor, ceiling, backWall, light, tallBlock2, shortBlock2
+    objs = d["objects"]
+    rect_index = {id(r): i for i, r in enumerate(d["rects"])}
+    for wall, wi in ((left, 0), (right, 1), (floor, 2), (ceiling, 3), (back, 4), (light, 5)):
+        o = _one(objs, world_index=wi)
+        assert (o.kind, o.xform, o.count) == (2, -1, 1) and d["rects"][o.first].k == wall.k and d["rects"][o.first].axis == wall.axis
+    # the blocks: six sides in Block::new's order (src/objects.rs:149-168): XY@zmin(+), XY@zmax(-), XZ@ymin(+), XZ@ymax(-), YZ@xmin(+), YZ@xmax(-)
+    for wi, (sx, sy, sz), degrees, offset in ((6, (165.0, 330.0, 165.0), 15.0, (265.0, 0.0, 295.0)),
+                                             (7, (165.0, 165.0, 165.0), -18.0, (130.0, 0.0, 65.0))):
+        o = _one(objs, world_index=wi)
+        assert (o.kind, o.count) == (2, 6) and o.xform >= 0
+        sides = [d["rects"][o.first + k] for k in range(6)]
+        want = [(2, 0.0, 1, 0.0, sx, 0.0, sy), (2, sz, 0, 0.0, sx, 0.0, sy), (1, 0.0, 1, 0.0, sx, 0.0, sz), (1, sy, 0, 0.0, sx, 0.0, sz),
+                (0, 0.0, 1, 0.0, sy, 0.0, sz), (0, sx, 0, 0.0, sy, 0.0, sz)]
+        for k, (s, w) in enumerate(zip(sides, want)):
+            assert (s.axis, s.k, s.facing_positive, s.a0, s.a1, s.b0, s.b1) == w and s.sub == k
+            assert material(s.material) == (LAMB, -1, (0.73, 0.73, 0.73))
+        # Translate(RotateY(block, degrees), offset): world -> object is p' = Ry (p - offset) with RotateY's forward
+        # map x' = c x - s z, z' = s x + c z (src/transforms.rs:194-203)
+        th = degrees * np.pi / 180.0
+        c, s = np.cos(th), np.sin(th)
+        m = np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]])
+        x = d["xforms"][o.xform]
+        assert np.allclose(np.array(x.m).reshape(3, 3), m, rtol=0, atol=1e-15)
+        assert np.allclose(np.array(x.b), -m @ np.array(offset), rtol=0, atol=1e-12)
+    assert np.allclose(np.array(d["xforms"][_one(objs, world_index=6).xform].b), [-179.61872566135948, 0.0, -353.53516570744313], atol=1e-9)
+    # camera (src/camera.rs:25-66): fov 40, aspect 1, focus 900 from (278, 278, -800) looking down +z
+    cam = d["camera"]
+    half = 900.0 * np.tan(np.radians(40.0) / 2)   # 327.5732108395821
+    assert tuple(cam.origin) == (278.0, 278.0, -800.0) and cam.lens_radius == 0.0 and (cam.start_time, cam.end_time) == (0.0, 1.0)
+    assert np.allclose(cam.horizontal, [-2 * half, 0, 0], atol=1e-10) and np.allclose(cam.vertical, [0, 2 * half, 0], atol=1e-10)
+    assert np.allclose(cam.lower_left_corner, [278 + half, 278 - half, 100.0], atol=1e-10)
+    assert np.allclose(cam.lower_left_corner, [605.5732108395822, -49.57321083958215, 100.0], atol=1e-9)
+    assert d["sky"].gradient == 0 and tuple(d["sky"].colour) == (0.0, 0.0, 0.0)
+
+
+def test_globe_flattens_to_the_values_written_by_hand(rt):
+    sc = rt.Scene.load(scene_path("globe"), ROOT)
+    d = _desc(sc)
+    (s,) = list(d["spheres"])
+    assert tuple(s.centre) == (0.0, 0.0, 0.0) and s.radius == 1.0
+    m = d["materials"][s.material]
+    assert m.type == 0 and m.image == 0     # lambertian over the image texture
+    (im,) = list(d["images"])
+    assert (im.width, im.height, im.texel_offset) == (1024, 512, 0)
+    # Spotlight (src/objects.rs:631-717): five panes over the box [(-w/2, -len, -w/2), (w/2, 0, w/2)], w = 0.3, len = 4:
+    # XY@zmin dark(+), XY@zmax dark(-), XZ@ymin LIGHT(+), YZ@xmin dark(+), YZ@xmax dark(-); no pane at y = 0
+    o = _one(d["objects"], world_index=1)
+    assert (o.kind, o.count) == (2, 5) and o.xform >= 0
+    panes = [d["rects"][o.first + k] for k in range(5)]
+    want = [(2, -0.15, 1, -0.15, 0.15, -4.0, 0.0), (2, 0.15, 0, -0.15, 0.15, -4.0, 0.0), (1, -4.0, 1, -0.15, 0.15, -0.15, 0.15),
+            (0, -0.15, 1, -4.0, 0.0, -0.15, 0.15), (0, 0.15, 0, -4.0, 0.0, -0.15, 0.15)]
+    for k, (p, w) in enumerate(zip(panes, want)):
+        assert (p.axis, p.k, p.facing_positive, p.a0, p.a1, p.b0, p.b1) == w and p.sub == k
+        pm = d["materials"][p.material]
+        if k == 2:
+            assert pm.type == 3 and tuple(pm.colour) == (9.0, 9.0, 2.0)      # DiffuseLight(light)
+        else:
+            assert pm.type == 0 and tuple(pm.colour) == (0.0, 0.0, 0.0)      # Lambertian(0, 0, 0)
+    # Translate(RotateY(RotateZ(prim, t1), t2), from), dir = at - from = (3, -3, 3):
+    # t1 = -acos(dot((0,1,0), unit(dir))), t2 = acos(dot((1,0,0), unit((dir.x, 0, dir.z)))) * -signum(dir.z)
+    t1 = -np.arccos(-1.0 / np.sqrt(3.0))
+    t2 = -np.arccos(1.0 / np.sqrt(2.0))
+    c1, s1, c2, s2 = np.cos(t1), np.sin(t1), np.cos(t2), np.sin(t2)
+    rz = np.array([[c1, s1, 0], [-s1, c1, 0], [0, 0, 1]])   # RotateZ forward: x' = s y + c x, y' = c y - s x (src/transforms.rs:285-294)
+    ry = np.array([[c2, 0, -s2], [0, 1, 0], [s2, 0, c2]])   # RotateY forward: x' = c x - s z, z' = s x + c z
+    mat = rz @ ry
+    x = d["xforms"][o.xform]
+    assert np.allclose(np.array(x.m).reshape(3, 3), mat, rtol=0, atol=1e-14)
+    assert np.allclose(np.array(x.b), -mat @ np.array([-3.0, 3.0, -3.0]), rtol=0, atol=1e-13)
+    # the housing lies behind lookFrom and the pane that glows (normal +y at y = -len) looks through the open end
+    # towards lookAt: object-space +y is the world direction from -> at
+    assert np.allclose(mat.T @ np.array([0, 1.0, 0]), np.array([3.0, -3.0, 3.0]) / np.sqrt(27.0), atol=1e-12)
+    sky = d["sky"]
+    assert sky.gradient == 1 and tuple(sky.unit_dir) == (0.0, 1.0, 0.0) and tuple(sky.colour1) == (0.05, 0.05, 0.05)
+    cam = d["camera"]
+    assert tuple(cam.origin) == (0.0, 0.0, -2.0)
+    assert np.allclose(cam.horizontal, [-2 * 900 * np.tan(np.radians(55.0)), 0, 0], rtol=1e-14)
+
+
+def test_obj_faces_flatten_to_the_vertices_written_by_hand(rt, tmp_path):
+    # wavefront_obj semantics restated (src/objects.rs:719-762): 1-based indices, polygons as fans around their first vertex,
+    # negative indices from the end, per-face normal = the first corner's `vn`, flipped to agree with cross(b - a, c - a)
+    obj = tmp_path / "quad.obj"
+    obj.write_text("v 0 0 0\nv 2 0 0\nv 2 3 0\nv 0 3 1\nvn 0 0 -1\nvn 0 0 1\nf 1//1 2//1 3//1 4//1\nf -1 -2 -4\n")
+    text = scene_text(objs='k: {type: "mesh", filename: "%s", material: "m"}' % obj, world='"k"')
+    sc = rt.Scene.from_text(text)
+    d = _desc(sc)
+    tris = list(d["triangles"])
+    assert len(tris) == 3
+    by_sub = {t.sub: t for t in tris}
+    t0, t1, t2 = by_sub[0], by_sub[1], by_sub[2]
+    assert (tuple(t0.point), tuple(t0.vec1), tuple(t0.vec2)) == ((0.0, 0.0, 0.0), (2.0, 0.0, 0.0), (2.0, 3.0, 0.0))     # (1, 2, 3)
+    assert (tuple(t1.point), tuple(t1.vec1), tuple(t1.vec2)) == ((0.0, 0.0, 0.0), (2.0, 3.0, 0.0), (0.0, 3.0, 1.0))     # (1, 3, 4)
+    assert (tuple(t2.point), tuple(t2.vec1), tuple(t2.vec2)) == ((0.0, 3.0, 1.0), (2.0, 0.0, -1.0), (0.0, -3.0, -1.0))  # (4, 3, 1)
+    # triangle 0: cross((2,0,0), (2,3,0)) = (0, 0, 6); the file's normal (0, 0, -1) points the other way and is flipped
+    assert tuple(t0.normal) == (0.0, 0.0, 1.0)
+    # triangle 2 has no normal index: unit(cross(vec1, vec2))
+    n = np.cross([2.0, 0.0, -1.0], [0.0, -3.0, -1.0])
+    assert np.allclose(tuple(t2.normal), n / np.linalg.norm(n), atol=1e-15)
