@@ -938,7 +938,9 @@ struct Engine : EngineBase {
             const char* e = std::getenv("RT_LANE_MIN_PATHS");
             return e ? (uint64_t)std::strtoull(e, nullptr, 10) : (uint64_t)8 << 20;
         }();
-        const int K = fixed ? 1
+        // While launches are timed one lane runs: a launch's duration is then its own, not stretched by the other lane's
+        // kernels on the same CUs (what the roofline of a kernel is priced with).
+        const int K = fixed || time_launches ? 1
                             : (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(lanes.size(), max_paths / npix),
                                                                              npix * ns / std::max<uint64_t>(1, lane_min_paths)));
         const uint64_t lane_paths = fixed ? (uint64_t)RT_NOALLOC_MAX_PATHS : std::max<uint64_t>(1, max_paths / (uint64_t)K);
