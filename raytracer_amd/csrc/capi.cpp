@@ -845,7 +845,11 @@ struct Engine : EngineBase {
     }
     int tail_grid_for(size_t n) {  // the tail launch hands paths out from a cursor: no more blocks than stay resident (RT_TAIL_WAVES per SIMD)
         size_t blocks = (n + 255) / 256;
-        const size_t cap = (size_t)num_cus * tail_blocks_per_cu;
+        static const int env_blocks = [] {
+            const char* e = std::getenv("RT_TAIL_BLOCKS");  // A/B runs of other RT_TAIL_WAVES builds
+            return e ? (int)std::strtol(e, nullptr, 10) : 0;
+        }();
+        const size_t cap = (size_t)num_cus * (env_blocks > 0 ? env_blocks : tail_blocks_per_cu);
         return (int)(blocks < 1 ? 1 : blocks > cap ? cap : blocks);
     }
     void need_scene() {
