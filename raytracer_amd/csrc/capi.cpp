@@ -670,6 +670,24 @@ struct Engine : EngineBase {
         S.sky.gradient = d.sky.gradient;
         cvt3(S.sky.colour, d.sky.colour); cvt3(S.sky.unit_dir, d.sky.unit_dir);
         cvt3(S.sky.colour0, d.sky.colour0); cvt3(S.sky.colour1, d.sky.colour1);
+        // bounding sphere of the world BVH (every box of every tree lies inside it) for far_shift
+        S.far_origin = INFINITY;
+        S.bound_centre[0] = S.bound_centre[1] = S.bound_centre[2] = (T)0;
+        S.bound_radius = (T)0;
+        if (d.tlas_root >= 0) {
+            const rt_node& root = d.nodes[d.tlas_root];
+            double r2 = 0;
+            bool finite = true;
+            for (int k = 0; k < 3; k++) {
+                if (!std::isfinite(root.lo[k]) || !std::isfinite(root.hi[k])) finite = false;
+                S.bound_centre[k] = (T)(0.5 * (root.lo[k] + root.hi[k]));
+                r2 += 0.25 * (root.hi[k] - root.lo[k]) * (root.hi[k] - root.lo[k]);
+            }
+            if (finite) {
+                S.bound_radius = (T)(std::sqrt(r2) * 1.001 + 1e-3 * scene_scale(d));
+                S.far_origin = far_origin_limit(d);
+            }
+        }
         // RT_ORDERED=0 (environment) walks trees in the reference's fixed left-first order (A/B runs).
         const char* ordered_env = std::getenv("RT_ORDERED");
         S.ordered = !(ordered_env && ordered_env[0] == '0');
@@ -849,7 +867,9 @@ struct Engine : EngineBase {
             const char* e = std::getenv("RT_TAIL_BLOCKS");  // A/B runs of other RT_TAIL_WAVES builds
             return e ? (int)std::strtol(e, nullptr, 10) : 0;
         }();
-        const size_t cap = (size_t)num_cus * (env_blocks > 0 ? env_blocks : tail_blocks_per_cu);
+        // blocks that stay resident per CU = the waves per SIMD the scene's tail kernel is compiled for (kernels.hip, tail_waves)
+        const int resident = S.n_sweep > 0 && S.lean ? 3 : S.nodes4 && S.has_meshes ? 4 : tail_blocks_per_cu;
+        const size_t cap = (size_t)num_cus * (env_blocks > 0 ? env_blocks : resident);
         return (int)(blocks < 1 ? 1 : blocks > cap ? cap : blocks);
     }
     void need_scene() {

@@ -390,12 +390,27 @@ __device__ __forceinline__ bool box_hit(const DNode<T>& n, V3<T> o, V3<T> inv_d,
 struct RayF {
     float ox, oy, oz, ix, iy, iz;
 };
+// `shift`: the box tests see the ray from the point o + shift d (far_shift below); 0 for every ray that starts near the scene.
 template <typename T>
-__device__ __forceinline__ RayF ray_f32(const Ray<T>& r) {
+__device__ __forceinline__ RayF ray_f32(const Ray<T>& r, float shift) {
     RayF f;
-    f.ox = (float)r.o.x; f.oy = (float)r.o.y; f.oz = (float)r.o.z;
+    f.ox = (float)(r.o.x + (T)shift * r.d.x); f.oy = (float)(r.o.y + (T)shift * r.d.y); f.oz = (float)(r.o.z + (T)shift * r.d.z);
     f.ix = 1.0f / (float)r.d.x; f.iy = 1.0f / (float)r.d.y; f.iz = 1.0f / (float)r.d.z;
     return f;
+}
+// The f32 box tests round the ray's origin to f32: an error of |o| 2^-24, which the padding of the boxes (8e-6 of the
+// scene's extent, tree_layout.hpp::box_pad) covers for origins within ~100 scene sizes.  A path scattered off an
+// unbounded Plane can start much further out.  Such a ray is looked at from a point further along its line, where it
+// comes within one radius of the bounding sphere of the world BVH (every box lies inside it; a ray that misses the
+// sphere hits no box, whatever the tests say): distances along the ray are then measured from there (t - shift), in
+// world space and - transforms are rigid, directions unit - in every object space alike.  Only box tests use it;
+// primitives are tested exactly, on the ray as it is.
+template <typename T>
+__device__ __forceinline__ float far_shift(const DScene<T>& S, const Ray<T>& r) {
+    const float m = fmaxf(fmaxf(fabsf((float)r.o.x), fabsf((float)r.o.y)), fabsf((float)r.o.z));
+    if (m <= S.far_origin) return 0.0f;
+    const T along = dot(ld3(S.bound_centre) - r.o, r.d) - S.bound_radius;
+    return along > (T)0.0 ? (float)along : 0.0f;
 }
 __device__ __forceinline__ float round_down(double x) { return __double2float_rd(x); }
 __device__ __forceinline__ float round_up(double x) { return __double2float_ru(x); }
@@ -465,11 +480,11 @@ struct DeepStack {
 // settles exact ties by the leaf's depth-first rank (DTriangle::dfs_rank, set when the scene is
 // uploaded).  `root` is a DNode2 whose child 0 is the reference's root.
 template <typename T, typename ST>
-__device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, ST st, int sp0,
+__device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, ST st, int sp0, float shift,
                          T* t_out, int* prim_out) {
-    const RayF f = ray_f32(r);
-    const float tmin32 = round_down(min_dist);
-    float bound32 = round_up(max_dist);
+    const RayF f = ray_f32(r, shift);
+    const float tmin32 = round_down(min_dist - (T)shift);
+    float bound32 = round_up(max_dist - (T)shift);
     int sp = sp0;
     int32_t next = root;
     bool found = false;
@@ -507,7 +522,7 @@ __device__ bool blas_hit(const DScene<T>& S, const Ray<T>& r, int root, T min_di
             if (triangle_hit(tr, r, min_dist, max_dist, &t)) {
                 if (!found || t < max_dist || tr.dfs_rank > best_rank) {
                     max_dist = t;
-                    bound32 = round_up(t);
+                    bound32 = round_up(t - (T)shift);
                     *prim_out = tri;
                     best_rank = tr.dfs_rank;
                     found = true;
@@ -620,11 +635,11 @@ __device__ __forceinline__ int32_t node4_step(const Node4Regs& n, const RayF& f,
 // reference's tree, the children that are hit are visited nearest first (S.ordered) or in the
 // reference's left-to-right order, exact ties go to the higher depth-first rank.
 template <typename T, typename ST>
-__device__ bool blas_hit4(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, ST st, int sp0,
-                          T* t_out, int* prim_out) {
-    const RayF f = ray_f32(r);
-    const float tmin32 = round_down(min_dist);
-    float bound32 = round_up(max_dist);
+__device__ bool blas_hit4(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, ST st, int sp0, float shift,
+                         T* t_out, int* prim_out) {
+    const RayF f = ray_f32(r, shift);
+    const float tmin32 = round_down(min_dist - (T)shift);
+    float bound32 = round_up(max_dist - (T)shift);
     int sp = sp0;
     int32_t next = root;
     bool found = false;
@@ -651,7 +666,7 @@ __device__ bool blas_hit4(const DScene<T>& S, const Ray<T>& r, int root, T min_d
             if (triangle_hit(tr, r, min_dist, max_dist, &t)) {
                 if (!found || t < max_dist || tr.dfs_rank > best_rank) {
                     max_dist = t;
-                    bound32 = round_up(t);
+                    bound32 = round_up(t - (T)shift);
                     *prim_out = tri;
                     best_rank = tr.dfs_rank;
                     found = true;
@@ -677,7 +692,7 @@ enum { FEAT_SPHERES = 1, FEAT_FLAT = 2 /* Triangle / Plane objects */, FEAT_BLAS
 
 template <typename T, bool UNIFORM, int FEAT, typename ST>
 __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist,
-                                  ST st, int sp, T* t_out, int* prim_out) {
+                                  ST st, int sp, float shift, T* t_out, int* prim_out) {
     const DObject ob = rec<UNIFORM>(&S.objects[oi]);
     Ray<T> r = world_ray;
     if (ob.xform >= 0) r = to_object_space(rec<UNIFORM>(&S.xforms[ob.xform]), world_ray);
@@ -714,8 +729,8 @@ __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& worl
     }
     if constexpr ((FEAT & FEAT_BLAS) != 0) {
         if (ob.kind == RT_OBJ_BLAS) {
-            if constexpr ((FEAT & FEAT_BLAS4) != 0) return blas_hit4(S, r, ob.first4, min_dist, max_dist, st, sp, t_out, prim_out);
-            else return blas_hit(S, r, ob.first, min_dist, max_dist, st, sp, t_out, prim_out);
+            if constexpr ((FEAT & FEAT_BLAS4) != 0) return blas_hit4(S, r, ob.first4, min_dist, max_dist, st, sp, shift, t_out, prim_out);
+            else return blas_hit(S, r, ob.first, min_dist, max_dist, st, sp, shift, t_out, prim_out);
         }
     }
     return false;
@@ -740,10 +755,10 @@ __device__ __noinline__ T medium_log_draw(PathRef path, uint32_t rng_key, uint32
 
 template <typename T, bool UNIFORM, int FEAT, typename ST>
 __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist, ST st,
-                           int sp, PathRef path, uint32_t depth, T* t_out, int* prim_out) {
+                           int sp, float shift, PathRef path, uint32_t depth, T* t_out, int* prim_out) {
     const DObject ob = rec<UNIFORM>(&S.objects[oi]);
     if ((FEAT & FEAT_MEDIA) == 0 || ob.kind != RT_OBJ_MEDIUM)
-        return simple_object_hit<T, UNIFORM, FEAT>(S, oi, world_ray, min_dist, max_dist, st, sp, t_out, prim_out);
+        return simple_object_hit<T, UNIFORM, FEAT>(S, oi, world_ray, min_dist, max_dist, st, sp, shift, t_out, prim_out);
     const DMedium<T> md = rec<UNIFORM>(&S.media[ob.first]);
     Ray<T> r = world_ray;
     if (ob.xform >= 0) r = to_object_space(rec<UNIFORM>(&S.xforms[ob.xform]), world_ray);
@@ -751,8 +766,8 @@ __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, 
     T t1, t2;
     int ignore;
     // (the second query runs only in the lanes whose first one hit, so it is not wave-uniform)
-    if (!simple_object_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, -inf, inf, st, sp, &t1, &ignore)) return false;
-    if (!simple_object_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, t1 + (T)0.0001, inf, st, sp, &t2, &ignore)) return false;
+    if (!simple_object_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, -inf, inf, st, sp, shift, &t1, &ignore)) return false;
+    if (!simple_object_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, t1 + (T)0.0001, inf, st, sp, shift, &t2, &ignore)) return false;
     if (t1 < min_dist) t1 = min_dist;
     if (t2 > max_dist) t2 = max_dist;
     if (t1 >= t2) return false;
@@ -791,13 +806,14 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
     bool have = false;
     T best_t = 0;
     Winner best{-1, -1};
+    const float shift = (SWEEP || MODE == WALK_OWN_BOX_LDS) && (FEAT & FEAT_BLAS) == 0 ? 0.0f : far_shift(S, ray);  // (box tests in f32 only)
     for (int e = 0; e < S.n_top; e++) {
         int entry = UNI ? rec<true>(&S.top_list[e]) : S.top_list[e];
         bool found = false;
         T t = 0;
         Winner w{-1, -1};
         if (entry != RT_TOP_BVH) {
-            found = object_hit<T, UNI, FEAT>(S, entry, ray, min_dist, max_dist, st, 0, path, depth, &t, &w.prim);
+            found = object_hit<T, UNI, FEAT>(S, entry, ray, min_dist, max_dist, st, 0, shift, path, depth, &t, &w.prim);
             w.obj = entry;
         } else if (SWEEP) {
             // Worlds of a few objects: no tree walk at all.  The leaves of the reference BVH are visited
@@ -828,7 +844,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                         hit = rects_hit_uniform(S, ray, ob.first, ob.count, min_dist, bound, &th, &prim);
                     }
                 } else {
-                    hit = object_hit<T, true, FEAT>(S, oi, ray, min_dist, bound, st, 0, path, depth, &th, &prim);
+                    hit = object_hit<T, true, FEAT>(S, oi, ray, min_dist, bound, st, 0, shift, path, depth, &th, &prim);
                 }
                 bound = hit ? th : bound;
                 w.obj = hit ? oi : w.obj;
@@ -850,7 +866,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                     int oi = -1 - left;
                     T th;
                     int prim;
-                    if (object_hit<T, false, FEAT>(S, oi, ray, min_dist, bound, st, sp, path, depth, &th, &prim)) {
+                    if (object_hit<T, false, FEAT>(S, oi, ray, min_dist, bound, st, sp, shift, path, depth, &th, &prim)) {
                         bound = th;
                         w.obj = oi;
                         w.prim = prim;
@@ -866,10 +882,10 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
             }
             t = bound;
         } else {
-            const RayF f = ray_f32(ray);
-            const float tmin32 = round_down(min_dist);
+            const RayF f = ray_f32(ray, shift);
+            const float tmin32 = round_down(min_dist - (T)shift);
             T bound = max_dist;
-            float bound32 = round_up(bound);
+            float bound32 = round_up(bound - (T)shift);
             int sp = 0;
             int32_t next = walks_node4(MODE) ? S.tlas_root4 : S.tlas_root;
             int32_t best_rank = -1;
@@ -884,13 +900,13 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                     const int oi = -1 - next;
                     T th;
                     int prim;
-                    if (object_hit<T, false, FEAT>(S, oi, ray, min_dist, bound, st, sp, path, depth, &th, &prim)) {
+                    if (object_hit<T, false, FEAT>(S, oi, ray, min_dist, bound, st, sp, shift, path, depth, &th, &prim)) {
                         // nearer-child-first walk (see blas_hit): among exactly equal distances the leaf
                         // that is last in the reference's depth-first order wins
                         const int32_t rank = S.objects[oi].dfs_rank;
                         if (!found || th < bound || rank > best_rank) {
                             bound = th;
-                            bound32 = round_up(th);
+                            bound32 = round_up(th - (T)shift);
                             w.obj = oi;
                             w.prim = prim;
                             best_rank = rank;
@@ -1074,9 +1090,17 @@ constexpr int BLOCK = 256;
 #define RT_XCD_RUN 16  // chunks of 256 rays per run of k_extend's XCD-aware order (16 = one 4096-slot tile); 0: every eighth chunk
 #endif
 #define RT_XCD_RUN_ (RT_XCD_RUN > 0 ? (uint32_t)RT_XCD_RUN : 1u)
-#ifndef RT_TAIL_WAVES
-#define RT_TAIL_WAVES 2
+// Waves per SIMD the tail launch (k_bounce<.., CAN_TAIL = true>) is compiled for, measured per kind of walk (2 / 3 / 4):
+// lean sweep 3 (cornell, 13 spp: 3.65 / 3.55 / 3.65 ms), mesh walks 4 (knight 44.96 / 44.16 / 43.78, 13 spp 9.78 /
+// 9.73 / 9.31), world trees without meshes 2 (blocks_ball 19.38 / 19.62 / 20.16).  capi.cpp sizes the grid to match
+// (Engine::tail_blocks_per_cu).  -DRT_TAIL_WAVES=n forces one value (A/B builds).
+constexpr int tail_waves(int mode) {
+#ifdef RT_TAIL_WAVES
+    return RT_TAIL_WAVES;
+#else
+    return mode == 3 /* WALK_SWEEP_LEAN */ ? 3 : (mode == 4 || mode == 5) /* WALK_NODE2_MESH4, WALK_NODE4_MESH */ ? 4 : 2;
 #endif
+}
 template <int MODE, bool DEEP = walks_node4(MODE)> struct StackFor {
     typedef Stack type;
     static constexpr int SPILL = 1;
@@ -1286,6 +1310,7 @@ struct Walk4 {
     int32_t best_rank;
     bool found;
     RayF f;       // current level
+    float shift;  // far_shift of the query
     float tmin32, bound32;
     int sp;
     int32_t next;
@@ -1303,9 +1328,10 @@ struct Walk4 {
         w = Winner{-1, -1};
         best_rank = -1;
         found = false;
-        f = ray_f32(r);
-        tmin32 = round_down(lo);
-        bound32 = round_up(hi);
+        shift = far_shift(S, r);
+        f = ray_f32(r, shift);
+        tmin32 = round_down(lo - (T)shift);
+        bound32 = round_up(hi - (T)shift);
         sp = 0;
         next = S.tlas_root4;
         in_mesh = false;
@@ -1327,8 +1353,8 @@ struct Walk4 {
                     found = true;
                 }
             }
-            f = ray_f32(ray);
-            bound32 = round_up(bound);
+            f = ray_f32(ray, shift);
+            bound32 = round_up(bound - (T)shift);
         }
         if (sp == 0) return false;
         next = st.get(--sp);
@@ -1346,7 +1372,7 @@ struct Walk4 {
             if (triangle_hit(tr, mr, min_dist, m_bound, &t)) {
                 if (!m_found || t < m_bound || tr.dfs_rank > m_rank) {
                     m_bound = t;
-                    bound32 = round_up(t);
+                    bound32 = round_up(t - (T)shift);
                     m_prim = tri;
                     m_rank = tr.dfs_rank;
                     m_found = true;
@@ -1359,7 +1385,7 @@ struct Walk4 {
             if ((FEAT & FEAT_BLAS) != 0 && ob.kind == RT_OBJ_BLAS) {  // enter the mesh (simple_object_hit's BLAS case)
                 mr = ray;
                 if (ob.xform >= 0) mr = to_object_space(S.xforms[ob.xform], ray);
-                f = ray_f32(mr);
+                f = ray_f32(mr, shift);
                 in_mesh = true;
                 m_sp0 = sp;
                 m_oi = oi;
@@ -1370,10 +1396,10 @@ struct Walk4 {
             } else {
                 T th;
                 int prim;
-                if (object_hit<T, false, LEAF_FEAT>(S, oi, ray, min_dist, bound, st, sp, path, depth, &th, &prim)) {
+                if (object_hit<T, false, LEAF_FEAT>(S, oi, ray, min_dist, bound, st, sp, shift, path, depth, &th, &prim)) {
                     if (!found || th < bound || ob.dfs_rank > best_rank) {
                         bound = th;
-                        bound32 = round_up(th);
+                        bound32 = round_up(th - (T)shift);
                         w = Winner{oi, prim};
                         best_rank = ob.dfs_rank;
                         found = true;
@@ -1423,7 +1449,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend_refill(DScene
                     T t = 0;
                     Winner w{-1, -1};
                     if (entry != RT_TOP_BVH) {
-                        found_here = object_hit<T, false, FEAT>(S, entry, walk.ray, walk.min_dist, max_dist, st, 0, path, depth, &t, &w.prim);
+                        found_here = object_hit<T, false, FEAT>(S, entry, walk.ray, walk.min_dist, max_dist, st, 0, walk.shift, path, depth, &t, &w.prim);
                         w.obj = entry;
                     } else {
                         found_here = walk.found;
@@ -1753,7 +1779,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DScene<T> S, DB
 // CAN_TAIL = true is the tail launch in the product (a few thousand waves, fewer than two per SIMD): it is
 // compiled for 2 waves per SIMD, i.e. up to 256 VGPRs, so that the walk + shading of a tree scene does not spill.
 template <typename T, int STACK, int MODE, bool CAN_TAIL>
-__global__ void __launch_bounds__(BLOCK, CAN_TAIL ? RT_TAIL_WAVES : RT_EXTEND_WAVES) k_bounce(DScene<T> S, DSmallScene small, DBatch B, DQueue<T> qin, DQueue<T> qout,
+__global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND_WAVES) k_bounce(DScene<T> S, DSmallScene small, DBatch B, DQueue<T> qin, DQueue<T> qout,
                                                                     T* sample_rgb, uint32_t depth0, uint32_t max_bounces,
                                                                     const uint32_t* __restrict__ tile_offsets,
                                                                     uint32_t* tile_counts_out, uint32_t n_tiles, DTail tail) {

@@ -18,7 +18,7 @@ namespace rt_layout {
 // camera and transform offsets included) exceeds that error by more than an order of magnitude
 // for every ray that starts inside the scene's extent, so the test never rejects a box the exact
 // f64 test of the reference accepts.
-inline float box_pad(const rt_scene_desc& d) {
+inline double scene_scale(const rt_scene_desc& d) {  // the largest coordinate a ray that starts on a bounded object can have
     double scale = 1e-30;
     auto take = [&](double x) {
         if (std::isfinite(x)) scale = std::max(scale, std::fabs(x));
@@ -31,8 +31,12 @@ inline float box_pad(const rt_scene_desc& d) {
     for (uint64_t i = 0; i < d.n_xforms; i++)
         for (int k = 0; k < 3; k++) take(d.xforms[i].b[k]);
     for (int k = 0; k < 3; k++) take(d.camera.origin[k]);
-    return (float)(8e-6 * scale);
+    return scale;
 }
+inline float box_pad(const rt_scene_desc& d) { return (float)(8e-6 * scene_scale(d)); }
+// Origins beyond this (paths scattered off an unbounded Plane) are outside what the padding covers (8e-6 / 2^-24 = 134
+// scene sizes): the kernels move them along the ray for the box tests (kernels.hip, far_shift).
+inline float far_origin_limit(const rt_scene_desc& d) { return (float)(32.0 * scene_scale(d)); }
 
 // One child slot of a DNode2 from reference node `idx`; returns the child reference.
 // Depth-first (left child first) rank of every leaf payload: the reference's BVHNode::hit lets the
