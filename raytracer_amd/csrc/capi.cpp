@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -437,17 +438,22 @@ struct Engine : EngineBase {
         LeafRanks ranks;
         ranks.object.assign(d.n_objects, 0);
         ranks.triangle.assign(d.n_triangles, 0);
-        {
-            std::vector<rtd::DNode2> v;
-            v.reserve(d.n_nodes / 2 + 8);
+        // (built by a task of its own while this thread regroups the four-wide trees below; uploaded after both)
+        std::vector<rtd::DNode2> v2;
+        std::future<void> nodes2_task = std::async(std::launch::async, [&] {
+            v2.reserve(d.n_nodes / 2 + 8);
             const float pad = box_pad(d);
-            if (d.tlas_root >= 0) root2[d.tlas_root] = build_nodes2(d, d.tlas_root, pad, v, ranks);
+            if (d.tlas_root >= 0) root2[d.tlas_root] = build_nodes2(d, d.tlas_root, pad, v2, ranks);
             for (uint64_t i = 0; i < d.n_objects; i++)
                 if (d.objects[i].kind == RT_OBJ_BLAS && root2[d.objects[i].first] < 0)
-                    root2[d.objects[i].first] = build_nodes2(d, d.objects[i].first, pad, v, ranks);
-            nodes2.upload(v);
-            n_nodes2 = v.size();
-        }
+                    root2[d.objects[i].first] = build_nodes2(d, d.objects[i].first, pad, v2, ranks);
+        });
+        struct Join {  // (an exception below must not leave the task running on locals that are gone)
+            std::future<void>& f;
+            ~Join() {
+                if (f.valid()) f.wait();
+            }
+        } join_nodes2{nodes2_task};
         // Four-wide mesh trees (RT_BVH4=0 in the environment keeps the binary walk for A/B runs).
         std::vector<int32_t> root4(d.n_nodes, -1);
         S.nodes4 = nullptr;
@@ -504,6 +510,10 @@ struct Engine : EngineBase {
                 }
             }
         }
+        nodes2_task.get();
+        nodes2.upload(v2);
+        n_nodes2 = v2.size();
+        std::vector<rtd::DNode2>().swap(v2);
         up_stats.ms_build = ms_since(t_build);  // (includes the copies of the two node arrays)
         const clock::time_point t_copy = clock::now();
         {
