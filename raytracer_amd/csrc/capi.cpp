@@ -476,8 +476,13 @@ struct Engine : EngineBase {
                 if ((e && e[0] == '0') || d.tlas_root < 0) break;
                 std::vector<rtd::WideNode4> v;
                 int need = 0, need_world = 0;
+                // RT_BVH8=1 (experiment; needs a library whose kernels were built with -DRT_BVH8): mesh trees eight wide
+                const char* wide8_env = std::getenv("RT_BVH8");
+                const bool wide8 = wide8_env && wide8_env[0] == '1';
+                if (wide8 && !use_sah) throw RtError{RT_ERR_UNSUPPORTED, "RT_BVH8: the eight-wide trees do not fit the traversal stack"};
                 auto build = [&](int32_t root, int* need_out) {
                     int32_t r = -1;
+                    if (use_sah && wide8 && root != d.tlas_root && build_sah8(d, root, pad, v, &r, need_out)) return r;
                     if (use_sah && build_sah4(d, root, pad, v, &r, need_out)) return r;
                     return build_nodes4(d, root, pad, v, need_out);
                 };

@@ -583,12 +583,12 @@ extern "C" void rt_exp_prof(unsigned long long* out, int reset) {
 // nearest first (or left to right), all but the first pushed - farthest first - and the first
 // returned (RT_EMPTY: none was hit).
 typedef float float2v __attribute__((ext_vector_type(2)));
-template <typename ST>
-__device__ __forceinline__ int32_t node4_step(const Node4Regs& n, const RayF& f, float tmin32, float bound32, bool ordered,
-                                              ST& st, int& sp) {
-    const float MISS = __int_as_float(0x7f800000);
-    float near[4] = {tmin32, tmin32, tmin32, tmin32};
-    float far[4] = {bound32, bound32, bound32, bound32};
+// Entry / exit distances of the four child boxes of `n` (intersected with [tmin32, bound32]).
+__device__ __forceinline__ void node4_boxes(const Node4Regs& n, const RayF& f, float tmin32, float bound32, float* near, float* far) {
+    for (int k = 0; k < 4; k++) {
+        near[k] = tmin32;
+        far[k] = bound32;
+    }
     const float o[3] = {f.ox, f.oy, f.oz}, inv[3] = {f.ix, f.iy, f.iz};
 #pragma unroll
     for (int axis = 0; axis < 3; axis++) {
@@ -606,6 +606,13 @@ __device__ __forceinline__ int32_t node4_step(const Node4Regs& n, const RayF& f,
             far[2 * pair + 1] = fminf(fmaxf(ta.y, tb.y), far[2 * pair + 1]);
         }
     }
+}
+template <typename ST>
+__device__ __forceinline__ int32_t node4_step(const Node4Regs& n, const RayF& f, float tmin32, float bound32, bool ordered,
+                                              ST& st, int& sp) {
+    const float MISS = __int_as_float(0x7f800000);
+    float near[4], far[4];
+    node4_boxes(n, f, tmin32, bound32, near, far);
     int32_t c0 = n.child(0), c1 = n.child(1), c2 = n.child(2), c3 = n.child(3);
     float k0 = ((c0 != RT_EMPTY) & (far[0] >= near[0])) ? (ordered ? near[0] : 0.0f) : MISS;
     float k1 = ((c1 != RT_EMPTY) & (far[1] >= near[1])) ? (ordered ? near[1] : 1.0f) : MISS;
@@ -631,6 +638,39 @@ __device__ __forceinline__ int32_t node4_step(const Node4Regs& n, const RayF& f,
     return k0 < MISS ? c0 : RT_EMPTY;
 }
 
+#ifdef RT_BVH8
+// Experiment: one step of an EIGHT-wide mesh walk.  A node is two consecutive DNode4 records (tree_layout.hpp,
+// build_sah8): 8 boxes, the hit children sorted nearest first (a 19-exchange network), seven pushed at most.
+template <typename ST>
+__device__ __forceinline__ int32_t node8_step(const Node4Regs& n0, const Node4Regs& n1, const RayF& f, float tmin32, float bound32,
+                                              bool ordered, ST& st, int& sp) {
+    const float MISS = __int_as_float(0x7f800000);
+    float near[8], far[8];
+    node4_boxes(n0, f, tmin32, bound32, near, far);
+    node4_boxes(n1, f, tmin32, bound32, near + 4, far + 4);
+    int32_t c[8];
+    float k[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c[i] = i < 4 ? n0.child(i) : n1.child(i - 4);
+        k[i] = ((c[i] != RT_EMPTY) & (far[i] >= near[i])) ? (ordered ? near[i] : (float)i) : MISS;
+    }
+#define RT_CE(a, b) order2(k[a], c[a], k[b], c[b])
+    RT_CE(0, 1); RT_CE(2, 3); RT_CE(4, 5); RT_CE(6, 7);
+    RT_CE(0, 2); RT_CE(1, 3); RT_CE(4, 6); RT_CE(5, 7);
+    RT_CE(1, 2); RT_CE(5, 6); RT_CE(0, 4); RT_CE(3, 7);
+    RT_CE(1, 5); RT_CE(2, 6);
+    RT_CE(1, 4); RT_CE(3, 6);
+    RT_CE(2, 4); RT_CE(3, 5);
+    RT_CE(3, 4);
+#undef RT_CE
+#pragma unroll
+    for (int i = 7; i >= 1; i--)
+        if (k[i] < MISS) st.put(sp++, c[i]);
+    return k[0] < MISS ? c[0] : RT_EMPTY;
+}
+#endif
+
 // The same walk as blas_hit over the four-wide tree: one 128-byte fetch decides two levels of the
 // reference's tree, the children that are hit are visited nearest first (S.ordered) or in the
 // reference's left-to-right order, exact ties go to the higher depth-first rank.
@@ -647,8 +687,13 @@ __device__ bool blas_hit4(const DScene<T>& S, const Ray<T>& r, int root, T min_d
     RT_PROF_DECL;
     for (;;) {
         RT_PROF(0);
+#ifdef RT_BVH8
+        const Node4Regs n = load_node4(S.nodes4, next), n_hi = load_node4(S.nodes4, next + 1);
+        next = node8_step(n, n_hi, f, tmin32, bound32, S.ordered != 0, st, sp);
+#else
         const Node4Regs n = load_node4(S.nodes4, next);
         next = node4_step(n, f, tmin32, bound32, S.ordered != 0, st, sp);
+#endif
         for (;;) {
             if (next == RT_EMPTY) {
                 if (sp == sp0) {

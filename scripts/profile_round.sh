@@ -15,7 +15,8 @@ for s in cornell knight blocks_ball; do
   timeout -k 10 300 $B --steps 5 --warmup 1 --scene $s > $O/bench_$s.json
   timeout -k 10 300 $B --steps 10 --warmup 2 --scene $s --spp 13 --no-cpu-baseline > $O/bench_${s}_13spp.json
 done
-timeout -k 10 300 $B --steps 3 --warmup 1 --scene globe --no-cpu-baseline > $O/bench_globe.json
+timeout -k 10 300 $B --steps 5 --warmup 1 --scene globe > $O/bench_globe.json
+timeout -k 10 300 $B --steps 5 --warmup 1 --scene two_spheres > $O/bench_two_spheres.json
 timeout -k 10 500 $B --steps 3 --warmup 1 --scene knight --triangles 1000000 > $O/bench_knight_1m.json
 echo "kernel stats"
 for s in cornell knight blocks_ball; do
