@@ -706,6 +706,11 @@ struct Engine : EngineBase {
         // RT_ORDERED=0 (environment) walks trees in the reference's fixed left-first order (A/B runs).
         const char* ordered_env = std::getenv("RT_ORDERED");
         S.ordered = !(ordered_env && ordered_env[0] == '0');
+        // RT_COOP=0: the tail launch walks meshes with one lane per path throughout (A/B runs; the image is the same).
+        // RT_COOP=n: groups of lanes answer a query in the tail launch while a wave has at most n live paths (0: never).
+        const char* coop_env = std::getenv("RT_COOP");
+        S.coop = coop_env ? std::max(0, std::min(32, std::atoi(coop_env))) : 16;
+        S.coop_reserve = stack_need4;
         S.has_meshes = S.has_media = 0;
         for (uint64_t i = 0; i < d.n_objects; i++) {
             if (d.objects[i].kind == RT_OBJ_BLAS) S.has_meshes = 1;

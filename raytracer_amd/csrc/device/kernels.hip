@@ -448,6 +448,7 @@ __device__ __forceinline__ Node2Regs load_node2(const DNode2* nodes, int idx) {
 // Per-lane traversal stack in LDS: entry e of lane l lives at stack[e * BLOCK + l], so the
 // 64 lanes of a wave touch 64 consecutive dwords (no bank conflicts).
 struct Stack {
+    static constexpr bool COOP = false;
     int32_t* base;
     int stride;
     __device__ __forceinline__ void put(int e, int32_t v) { base[e * stride] = v; }
@@ -458,6 +459,7 @@ struct Stack {
 // The same with a private array behind it for entries beyond `cap`: a four-wide walk keeps up to 3
 // siblings per level on the stack, which in its worst visiting order is more than the LDS part holds.
 struct DeepStack {
+    static constexpr bool COOP = false;
     int32_t* base;
     int stride;
     int cap;
@@ -469,6 +471,13 @@ struct DeepStack {
     __device__ __forceinline__ int32_t get(int e) const { return e < cap ? base[e * stride] : overflow[e - cap]; }
     __device__ __forceinline__ bool room(int e, int n) const { return e + n <= cap; }  // entries e .. e+n-1 are in LDS
     __device__ __forceinline__ void put_near(int e, int32_t v) { base[e * stride] = v; }
+};
+// A DeepStack held by each lane of a GROUP of `group` neighbouring lanes (a power of two, aligned) that carry the
+// same ray: the walk down to a mesh is the same in every lane, and the mesh walk itself is shared out over the
+// group (blas_hit4_group), which uses the LDS rows above the caller's entries in all the group's columns.
+struct GroupStack : DeepStack {
+    static constexpr bool COOP = true;
+    int group;
 };
 
 // BVHNode::hit over a triangle BVH (src/hitting.rs:211-229).  The reference's recursion "left with
@@ -557,6 +566,25 @@ __device__ __forceinline__ void order2(float& ka, int32_t& ca, float& kb, int32_
     ka = k0; kb = k1; ca = c0; cb = c1;
 }
 
+#if defined(RT_EXP) && (RT_EXP & 256)
+__device__ unsigned long long g_live_hist[65];
+extern "C" void rt_exp_live(unsigned long long* out, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_live_hist), sizeof(g_live_hist));
+    if (reset) {
+        unsigned long long z[65] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_live_hist), z, sizeof(z));
+    }
+}
+// per wave of the tail launch: the clock (100 MHz) when it started, when the queue ran dry for it, when it ended
+__device__ unsigned long long g_wave_clock[3][8192];
+extern "C" void rt_exp_wave_clock(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_clock), sizeof(g_wave_clock));
+    static unsigned long long z[3][8192];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_clock), z, sizeof(z));
+}
+#endif
 #if defined(RT_EXP) && (RT_EXP & 32)  // measurement only: lane / wave step counts of the four-wide walks (scripts/exp_steps.py)
 __device__ unsigned long long g_prof[8];
 #define RT_PROF_DECL uint32_t prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -675,8 +703,8 @@ __device__ __forceinline__ int32_t node8_step(const Node4Regs& n0, const Node4Re
 // reference's tree, the children that are hit are visited nearest first (S.ordered) or in the
 // reference's left-to-right order, exact ties go to the higher depth-first rank.
 template <typename T, typename ST>
-__device__ bool blas_hit4(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, ST st, int sp0, float shift,
-                         T* t_out, int* prim_out) {
+__device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, ST st, int sp0, float shift,
+                              T* t_out, int* prim_out) {
     const RayF f = ray_f32(r, shift);
     const float tmin32 = round_down(min_dist - (T)shift);
     float bound32 = round_up(max_dist - (T)shift);
@@ -722,6 +750,118 @@ __device__ bool blas_hit4(const DScene<T>& S, const Ray<T>& r, int root, T min_d
     }
     *t_out = max_dist;
     return found;
+}
+
+// The same query answered by a group of lanes that all hold the same ray (GroupStack): the nodes and leaves that
+// are still to be visited sit in a frontier in LDS, and every round the group takes up to `group` of them off its
+// end, one per lane: a node's lane tests its four boxes and appends the children that are hit, a leaf's lane runs
+// the exact triangle test.  The answer is the one of the one-lane walk, bit for bit: that is "the smallest t, among
+// equal t the highest depth-first rank" over the leaves the ray hits inside [min, max], whatever the order of the
+// visits (see blas_hit); culling by the current bound only ever drops subtrees that hold no such leaf (t == bound
+// passes the box test, which is conservative).  A path's tail of bounces is walked by one lane per wave at the
+// end of the tail launch: with 64 lanes per ray the chain of dependent fetches is as long as the tree is deep
+// instead of as long as the walk.
+template <typename T, typename ST>
+__device__ bool blas_hit4_group(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, ST st, int sp0, float shift,
+                               T* t_out, int* prim_out) {
+    const int G = st.group;
+    const int lane = threadIdx.x & 63, gl = lane & (G - 1);
+    const uint64_t gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane - gl);
+    const uint64_t below = gmask & ((1ull << lane) - 1ull);  // the lanes of my group before me
+    const int fcap = (st.cap - sp0) * G;                     // frontier entries the group's free LDS rows hold
+    // (entry e: row sp0 + e / G of the column of the group's lane e % G)
+    auto slot = [&](int e) -> int32_t* { return st.base + (sp0 + e / G) * st.stride + ((e & (G - 1)) - gl); };
+    // A frontier that could outgrow its rows is walked depth first by one entry a round: that needs no more than the
+    // one-lane walk does (S.coop_reserve entries: 3 per level of the deepest four-wide tree of the scene).
+    const int reserve = S.coop_reserve;
+    if (fcap < 2 * reserve + 4 * G) return blas_hit4_lane(S, r, root, min_dist, max_dist, (DeepStack)st, sp0, shift, t_out, prim_out);
+    const RayF f = ray_f32(r, shift);
+    const float tmin32 = round_down(min_dist - (T)shift);
+    float bound32 = round_up(max_dist - (T)shift);
+    const float MISS = __int_as_float(0x7f800000);
+    int count = 1;
+    if (gl == 0) *slot(0) = root;
+    bool found = false;
+    int32_t best_rank = -1;
+    int best_prim = -1;
+    while (count > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int n = count < G ? count : G;
+        if (count + 3 * n > fcap - reserve) n = 1;
+        const bool active = gl < n;
+        const int32_t ref = active ? *slot(count - n + gl) : RT_EMPTY;
+        count -= n;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int32_t c[4] = {RT_EMPTY, RT_EMPTY, RT_EMPTY, RT_EMPTY};
+        float key[4] = {MISS, MISS, MISS, MISS};
+        T t = max_dist;
+        int32_t rank = -1;
+        int prim = -1;
+        bool hit = false;
+        if (ref >= 0) {
+            const Node4Regs nd = load_node4(S.nodes4, ref);
+            float near[4], far[4];
+            node4_boxes(nd, f, tmin32, bound32, near, far);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                c[k] = nd.child(k);
+                key[k] = ((c[k] != RT_EMPTY) & (far[k] >= near[k])) ? near[k] : MISS;
+            }
+            // farthest first: the nearest boxes end up at the frontier's end and are taken first
+            order2(key[0], c[0], key[1], c[1]);
+            order2(key[2], c[2], key[3], c[3]);
+            order2(key[0], c[0], key[2], c[2]);
+            order2(key[1], c[1], key[3], c[3]);
+            order2(key[1], c[1], key[2], c[2]);
+        } else if (ref != RT_EMPTY) {
+            const int tri = -1 - ref;
+            const DTriangle<T> tr = S.triangles[tri];
+            T th;
+            if (triangle_hit(tr, r, min_dist, max_dist, &th)) {
+                hit = true;
+                t = th;
+                rank = tr.dfs_rank;
+                prim = tri;
+            }
+        }
+        // the round's best leaf: smallest t, then highest rank
+        for (int off = G >> 1; off > 0; off >>= 1) {
+            const bool o_hit = __shfl_xor((int)hit, off) != 0;
+            const T o_t = __shfl_xor(t, off);
+            const int32_t o_rank = __shfl_xor(rank, off);
+            const int o_prim = __shfl_xor(prim, off);
+            if (o_hit && (!hit || o_t < t || (o_t == t && o_rank > rank))) {
+                hit = true; t = o_t; rank = o_rank; prim = o_prim;
+            }
+        }
+        if (hit && (!found || t < max_dist || rank > best_rank)) {
+            max_dist = t;
+            bound32 = round_up(t - (T)shift);
+            best_prim = prim;
+            best_rank = rank;
+            found = true;
+        }
+        // append the children that are still inside the bound (slot 3 holds the farthest of a node)
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const bool push = key[k] < MISS && key[k] <= bound32;
+            const uint64_t m = __ballot(push) & gmask;
+            if (push) *slot(count + __popcll(m & below)) = c[k];
+            count += __popcll(m);
+        }
+    }
+    *t_out = max_dist;
+    if (found) *prim_out = best_prim;
+    return found;
+}
+
+template <typename T, typename ST>
+__device__ __forceinline__ bool blas_hit4(const DScene<T>& S, const Ray<T>& r, int root, T min_dist, T max_dist, ST st, int sp0,
+                                          float shift, T* t_out, int* prim_out) {
+    if constexpr (ST::COOP) return blas_hit4_group(S, r, root, min_dist, max_dist, st, sp0, shift, t_out, prim_out);
+    else return blas_hit4_lane(S, r, root, min_dist, max_dist, st, sp0, shift, t_out, prim_out);
 }
 
 struct Winner {
@@ -1842,13 +1982,21 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t total = tile_offsets[n_tiles];
     // One bounce of one path: the closest-hit query, the hit record, the shading.
-    auto bounce_once = [&](const Ray<T>& ray, V3<T>& thr, uint32_t pid, uint32_t depth, Ray<T>& nr) -> bool {
+    // (known != nullptr: the closest-hit query has been answered already, by the lane's group)
+    struct Answer { bool hit; T t; Winner w; };
+    auto bounce_once = [&](const Ray<T>& ray, V3<T>& thr, uint32_t pid, uint32_t depth, Ray<T>& nr, const Answer* known = nullptr) -> bool {
         const PathRef path{&B, pid};
         T t = 0, u = 0, v = 0;
         V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
         uint32_t mf = RT_MISS;
         Winner w;
-        if (closest_hit<T, MODE>(W, ray, (T)0.001, Lim<T>::inf(), st, path, depth, &t, &w)) {  // src/hitting.rs:20-21
+        bool hit;
+        if (known) {
+            hit = known->hit; t = known->t; w = known->w;
+        } else {
+            hit = closest_hit<T, MODE>(W, ray, (T)0.001, Lim<T>::inf(), st, path, depth, &t, &w);  // src/hitting.rs:20-21
+        }
+        if (hit) {
 #if defined(RT_EXP) && (RT_EXP & 16)  // timing experiment only: no surface reconstruction
             n = mk((T)0.0, (T)1.0, (T)0.0);
             mf = (uint32_t)W.rects[w.prim].material | 0x80000000u;
@@ -1886,6 +2034,7 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
         // lane whose path has ended takes the next one of the share, so the waves stay full until the queue is
         // empty, and the launch ends as long after that as its longest path.
         uint32_t extra_queries = 0, deepest = depth0, taken = 0;
+        constexpr bool COOP_MODE = MODE == WALK_NODE2_MESH4 || MODE == WALK_NODE4_MESH;
         const uint32_t CHUNK = max(64u, min(1024u, (total / (gridDim.x * (BLOCK / 64) * 8u)) & ~63u));
         uint32_t chunk_lo = 0, chunk_hi = 0;  // (wave-uniform) what is left of the wave's share
         bool exhausted = false;               // (wave-uniform)
@@ -1895,6 +2044,11 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
         uint32_t pid = 0, depth = depth0;
         ray.o = ray.d = thr = mk((T)0.0, (T)0.0, (T)0.0);
         ray.time = (T)0.0;
+#if defined(RT_EXP) && (RT_EXP & 256)
+        const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+        bool noted = false;
+        if (lane == 0 && wave_id < 8192) g_wave_clock[0][wave_id] = wall_clock64();
+#endif
         for (;;) {
             while (!exhausted) {
                 const uint64_t idle = __ballot(!alive);
@@ -1924,16 +2078,67 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
                 }
                 chunk_lo += min((uint32_t)__popcll(idle), avail);
             }
+#if defined(RT_EXP) && (RT_EXP & 256)
+            if (exhausted && !noted) {
+                noted = true;
+                if (lane == 0 && wave_id < 8192) g_wave_clock[1][wave_id] = wall_clock64();
+            }
+#endif
             if (__ballot(alive) == 0) break;
+#if defined(RT_EXP) && (RT_EXP & 256)  // measurement only: live lanes per wave and iteration of the tail launch (scripts/exp_tail_live.py)
+            {
+                const int live_now = __popcll(__ballot(alive));
+                if (lane == 0) atomicAdd(&g_live_hist[live_now], 1ull);
+            }
+#endif
+            // A wave with a few live lanes left (the end of the launch is waves of ONE path each, walking the mesh at
+            // one lane's pace): each live path's query is answered by a group of 64 / 32 / 16 / 8 lanes.
+            Answer ans;
+            bool grouped = false;
+            if constexpr (COOP_MODE) {
+                const uint64_t live = __ballot(alive);
+                const int n_live = __popcll(live);
+                if (n_live <= S.coop) {  // (wave-uniform)
+                    const int G = n_live <= 1 ? 64 : n_live <= 2 ? 32 : n_live <= 4 ? 16 : n_live <= 8 ? 8 : n_live <= 16 ? 4 : 2;
+                    const int group = (int)lane / G;
+                    uint64_t rest = live;
+                    for (int k = 0; k < group && rest; k++) rest &= rest - 1;
+                    const bool has_ray = rest != 0;
+                    const int owner = has_ray ? __ffsll((long long)rest) - 1 : 0;  // the group-th live lane
+                    Ray<T> gr;
+                    gr.o = mk(__shfl(ray.o.x, owner), __shfl(ray.o.y, owner), __shfl(ray.o.z, owner));
+                    gr.d = mk(__shfl(ray.d.x, owner), __shfl(ray.d.y, owner), __shfl(ray.d.z, owner));
+                    gr.time = __shfl(ray.time, owner);
+                    const uint32_t g_pid = (uint32_t)__shfl((int)pid, owner), g_depth = (uint32_t)__shfl((int)depth, owner);
+                    T g_t = 0;
+                    Winner g_w{-1, -1};
+                    bool g_hit = false;
+                    if (has_ray) {
+                        GroupStack gs;
+                        gs.base = st.base; gs.stride = st.stride; gs.cap = st.cap; gs.overflow = st.overflow; gs.group = G;
+                        g_hit = closest_hit<T, MODE>(W, gr, (T)0.001, Lim<T>::inf(), gs, PathRef{&B, g_pid}, g_depth, &g_t, &g_w);
+                    }
+                    // back to the path's own lane: the k-th live lane reads lane 0 of group k
+                    const int from = __popcll(live & ((1ull << lane) - 1ull)) * G;
+                    ans.hit = __shfl((int)g_hit, from & 63) != 0;
+                    ans.t = __shfl(g_t, from & 63);
+                    ans.w.obj = __shfl(g_w.obj, from & 63);
+                    ans.w.prim = __shfl(g_w.prim, from & 63);
+                    grouped = true;
+                }
+            }
             if (alive) {
                 Ray<T> nr;
                 if (depth > depth0) extra_queries++;
                 deepest = max(deepest, depth + 1);
-                alive = bounce_once(ray, thr, pid, depth, nr);
+                alive = bounce_once(ray, thr, pid, depth, nr, grouped ? &ans : nullptr);
                 ray = nr;  // the scattered ray is the next bounce's query
                 depth++;
             }
         }
+#if defined(RT_EXP) && (RT_EXP & 256)
+        if (lane == 0 && wave_id < 8192) g_wave_clock[2][wave_id] = wall_clock64();
+#endif
         // rays and depth statistics of the bounces that were not launches
         for (int off = 32; off > 0; off >>= 1) {
             extra_queries += __shfl_xor(extra_queries, off);

@@ -160,6 +160,9 @@ struct DScene {
     int32_t stack_cap;   // > 0: entries of the LDS stack a four-wide walk may use before it overflows (tests)
     int32_t has_meshes, has_media;  // object kinds present: pick the four-wide kernel compiled for them
     int32_t emit_once;  // no checker has a light among its parts: a path adds to its sample at most once, when it ends (plain store)
+    // The tail launch answers the queries of a wave that has at most `coop` live paths left by groups of lanes
+    // (blas_hit4_group); coop_reserve: stack entries a one-lane walk of the scene's trees can need.
+    int32_t coop, coop_reserve;
     // Rays that start further than far_origin from the origin of coordinates (paths scattered off an unbounded Plane)
     // are moved along their line to the bounding sphere of the world BVH for the f32 box tests (kernels.hip, far_shift):
     // the padding of the boxes only covers the f32 rounding of origins near the scene.
