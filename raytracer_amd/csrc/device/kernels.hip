@@ -577,6 +577,13 @@ extern "C" void rt_exp_live(unsigned long long* out, int reset) {
     }
 }
 // per wave of the tail launch: the clock (100 MHz) when it started, when the queue ran dry for it, when it ended
+__device__ unsigned long long g_live_ticks[65];  // clock ticks spent in iterations with that many live lanes
+extern "C" void rt_exp_live_ticks(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_live_ticks), sizeof(g_live_ticks));
+    unsigned long long z[65] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_live_ticks), z, sizeof(z));
+}
 __device__ unsigned long long g_wave_clock[3][8192];
 extern "C" void rt_exp_wave_clock(unsigned long long* out) {
     (void)hipDeviceSynchronize();
@@ -584,6 +591,31 @@ extern "C" void rt_exp_wave_clock(unsigned long long* out) {
     static unsigned long long z[3][8192];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_clock), z, sizeof(z));
 }
+#endif
+#if defined(RT_EXP) && (RT_EXP & 1024)  // measurement only: steps (nodes + leaves, both levels) per ray of k_extend, and per wave the longest
+__shared__ uint32_t g_lane_steps[256];
+__device__ unsigned long long g_step_hist[2048], g_wave_longest[2];  // [sum over waves of the longest walk, waves]
+// "stop a wave's walks after C steps": sum over waves of min(longest, C), and the histogram of what is left per ray
+__device__ unsigned long long g_cut_first[5], g_cut_left[5][2048];
+extern "C" void rt_exp_cut_hist(unsigned long long* first, unsigned long long* left) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(first, HIP_SYMBOL(g_cut_first), sizeof(g_cut_first));
+    (void)hipMemcpyFromSymbol(left, HIP_SYMBOL(g_cut_left), sizeof(g_cut_left));
+    static unsigned long long z[5][2048];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_first), z, sizeof(g_cut_first));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_left), z, sizeof(g_cut_left));
+}
+#define RT_STEP_COUNT g_lane_steps[threadIdx.x]++
+extern "C" void rt_exp_step_hist(unsigned long long* hist, unsigned long long* waves) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_step_hist), sizeof(g_step_hist));
+    (void)hipMemcpyFromSymbol(waves, HIP_SYMBOL(g_wave_longest), sizeof(g_wave_longest));
+    static unsigned long long z[2048];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_hist), z, sizeof(g_step_hist));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_longest), z, sizeof(g_wave_longest));
+}
+#else
+#define RT_STEP_COUNT
 #endif
 #if defined(RT_EXP) && (RT_EXP & 32)  // measurement only: lane / wave step counts of the four-wide walks (scripts/exp_steps.py)
 __device__ unsigned long long g_prof[8];
@@ -715,6 +747,7 @@ __device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T 
     RT_PROF_DECL;
     for (;;) {
         RT_PROF(0);
+        RT_STEP_COUNT;
 #ifdef RT_BVH8
         const Node4Regs n = load_node4(S.nodes4, next), n_hi = load_node4(S.nodes4, next + 1);
         next = node8_step(n, n_hi, f, tmin32, bound32, S.ordered != 0, st, sp);
@@ -733,10 +766,22 @@ __device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T 
             }
             if (next >= 0) break;
             RT_PROF(2);
+            RT_STEP_COUNT;
             const int tri = -1 - next;  // leaf: the exact test, against the current bound (t == bound passes)
             T t;
             const DTriangle<T> tr = S.triangles[tri];
+#if defined(RT_EXP) && (RT_EXP & 512)  // timing experiment only: the triangle test in f32 arithmetic (what the f64 arithmetic of the leaves costs)
+            V3<float> sf;
+            bool hit_f = line_plane_collision(V3<float>{(float)r.o.x, (float)r.o.y, (float)r.o.z}, V3<float>{(float)r.d.x, (float)r.d.y, (float)r.d.z},
+                                              V3<float>{(float)tr.point[0], (float)tr.point[1], (float)tr.point[2]},
+                                              V3<float>{(float)tr.vec1[0], (float)tr.vec1[1], (float)tr.vec1[2]},
+                                              V3<float>{(float)tr.vec2[0], (float)tr.vec2[1], (float)tr.vec2[2]}, &sf);
+            hit_f = hit_f && !(sf.x < (float)min_dist || sf.x > (float)max_dist) && !(sf.y < 0.0f || sf.z < 0.0f || sf.y + sf.z > 1.0f);
+            t = (T)sf.x;
+            if (hit_f) {
+#else
             if (triangle_hit(tr, r, min_dist, max_dist, &t)) {
+#endif
                 if (!found || t < max_dist || tr.dfs_rank > best_rank) {
                     max_dist = t;
                     bound32 = round_up(t - (T)shift);
@@ -826,22 +871,20 @@ __device__ bool blas_hit4_group(const DScene<T>& S, const Ray<T>& r, int root, T
                 prim = tri;
             }
         }
-        // the round's best leaf: smallest t, then highest rank
-        for (int off = G >> 1; off > 0; off >>= 1) {
-            const bool o_hit = __shfl_xor((int)hit, off) != 0;
-            const T o_t = __shfl_xor(t, off);
-            const int32_t o_rank = __shfl_xor(rank, off);
-            const int o_prim = __shfl_xor(prim, off);
-            if (o_hit && (!hit || o_t < t || (o_t == t && o_rank > rank))) {
-                hit = true; t = o_t; rank = o_rank; prim = o_prim;
+        // the round's hits, one after the other (a round rarely has more than one or two; most have none), each
+        // under the rule of the one-lane walk: nearer wins, the higher rank among equal distances
+        for (uint64_t hits = __ballot(hit) & gmask; hits; hits &= hits - 1) {
+            const int from = __ffsll((long long)hits) - 1;
+            const T o_t = __shfl(t, from);
+            const int32_t o_rank = __shfl(rank, from);
+            const int o_prim = __shfl(prim, from);
+            if (o_t <= max_dist && (!found || o_t < max_dist || o_rank > best_rank)) {  // (the bound may have moved since the test)
+                max_dist = o_t;
+                bound32 = round_up(o_t - (T)shift);
+                best_prim = o_prim;
+                best_rank = o_rank;
+                found = true;
             }
-        }
-        if (hit && (!found || t < max_dist || rank > best_rank)) {
-            max_dist = t;
-            bound32 = round_up(t - (T)shift);
-            best_prim = prim;
-            best_rank = rank;
-            found = true;
         }
         // append the children that are still inside the bound (slot 3 holds the farthest of a node)
 #pragma unroll
@@ -1082,6 +1125,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                 }
                 if (next < 0) {
                     RT_PROF(4);
+                    RT_STEP_COUNT;
                     const int oi = -1 - next;
                     T th;
                     int prim;
@@ -1101,6 +1145,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                     next = RT_EMPTY;
                 } else if constexpr (walks_node4(MODE)) {  // four-wide step, as in blas_hit4
                     RT_PROF(6);
+                    RT_STEP_COUNT;
                     const Node4Regs n = load_node4(S.nodes4, next);
                     next = node4_step(n, f, tmin32, bound32, S.ordered != 0, st, sp);
                 } else {
@@ -1457,7 +1502,27 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
         T max_dist = tmax_arr ? tmax_arr[i] : Lim<T>::inf();
         T t;
         Winner w;
+#if defined(RT_EXP) && (RT_EXP & 1024)
+        g_lane_steps[threadIdx.x] = 0;
+        const bool got = closest_hit<T, MODE>(S, r, min_dist, max_dist, st, path, depth, &t, &w);
+        {
+            const uint32_t steps = g_lane_steps[threadIdx.x];
+            atomicAdd(&g_step_hist[min(steps, 2047u)], 1ull);
+            uint32_t longest = steps;
+            for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
+            const uint32_t cuts[5] = {8, 16, 24, 32, 48};
+            for (int c = 0; c < 5; c++)
+                if (steps > cuts[c]) atomicAdd(&g_cut_left[c][min(steps - cuts[c], 2047u)], 1ull);
+            if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) {
+                atomicAdd(&g_wave_longest[0], (unsigned long long)longest);
+                atomicAdd(&g_wave_longest[1], 1ull);
+                for (int c = 0; c < 5; c++) atomicAdd(&g_cut_first[c], (unsigned long long)min(longest, cuts[c]));
+            }
+        }
+        if (got) {
+#else
         if (closest_hit<T, MODE>(S, r, min_dist, max_dist, st, path, depth, &t, &w)) {
+#endif
             Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(S, r, t, w, S.needs_uv != 0 || h.owner != nullptr);
             h.t[i] = t;
             h.nx[i] = sf.normal.x; h.ny[i] = sf.normal.y; h.nz[i] = sf.normal.z;
@@ -2086,10 +2151,9 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
 #endif
             if (__ballot(alive) == 0) break;
 #if defined(RT_EXP) && (RT_EXP & 256)  // measurement only: live lanes per wave and iteration of the tail launch (scripts/exp_tail_live.py)
-            {
-                const int live_now = __popcll(__ballot(alive));
-                if (lane == 0) atomicAdd(&g_live_hist[live_now], 1ull);
-            }
+            const int live_now = __popcll(__ballot(alive));
+            const unsigned long long tick0 = wall_clock64();
+            if (lane == 0) atomicAdd(&g_live_hist[live_now], 1ull);
 #endif
             // A wave with a few live lanes left (the end of the launch is waves of ONE path each, walking the mesh at
             // one lane's pace): each live path's query is answered by a group of 64 / 32 / 16 / 8 lanes.
@@ -2135,6 +2199,9 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
                 ray = nr;  // the scattered ray is the next bounce's query
                 depth++;
             }
+#if defined(RT_EXP) && (RT_EXP & 256)
+            if (lane == 0) atomicAdd(&g_live_ticks[live_now], wall_clock64() - tick0);
+#endif
         }
 #if defined(RT_EXP) && (RT_EXP & 256)
         if (lane == 0 && wave_id < 8192) g_wave_clock[2][wave_id] = wall_clock64();

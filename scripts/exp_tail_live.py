@@ -27,6 +27,8 @@ out = (C.c_ulonglong * 65)()
 lib.rt_exp_live(out, 1)
 clocks = (C.c_ulonglong * (3 * 8192))()
 lib.rt_exp_wave_clock(clocks)
+ticks = (C.c_ulonglong * 65)()
+lib.rt_exp_live_ticks(ticks)
 r.render_rows(W, H, 0, H, spp, 50, seed=0, want_sums=False)
 lib.rt_exp_live(out, 1)
 h = list(out)
@@ -37,6 +39,12 @@ for k in range(1, 65):
     cum += h[k]
     if k in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64):
         print(f"  <= {k:2d} live lanes: {cum / total * 100:5.1f} % of the wave-iterations")
+lib.rt_exp_live_ticks(ticks)
+tk = list(ticks)
+for lo, hi in ((1, 1), (2, 2), (3, 4), (5, 8), (9, 16), (17, 32), (33, 63), (64, 64)):
+    n = sum(h[lo:hi + 1])
+    if n:
+        print(f"  iterations with {lo:2d}..{hi:2d} live lanes: {sum(tk[lo:hi + 1]) / n / 100.0:7.1f} us each ({n} of them)")
 
 # when the waves of the (last) tail launch started, saw the queue run dry, and ended
 lib.rt_exp_wave_clock(clocks)
