@@ -2020,7 +2020,13 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DScene<T> S, DB
                 }
                 n = mk(h.nx[i], h.ny[i], h.nz[i]);
             }
+#if defined(RT_EXP) && (RT_EXP & 2048)  // timing experiment only: what k_shade costs with no shading in it (its memory floor)
+            alive = mf != RT_MISS && depth + 1 < max_bounces;
+            nr.o = ray.at(t); nr.d = n; nr.time = ray.time;
+            if (mf == RT_MISS) sample_rgb[(uint64_t)pid * 3] = thr.x;
+#else
             alive = shade_path(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
+#endif
         }
         compact_store(alive, tile, nr, thr, pid, qout, tile_counts_out);
     }
