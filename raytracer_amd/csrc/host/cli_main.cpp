@@ -10,7 +10,7 @@
 //    thread_rng, so its images are not reproducible; without --seed ours are not either).
 //  * the monitor thread is always joined (the reference skips the join under --quiet and can exit
 //    before the part file is removed).
-//  * .png, .jpg/.jpeg, .ppm/.pnm and .bmp outputs are encoded (image_out.cpp); the image crate's other formats are not.
+//  * .png, .jpg/.jpeg, .ppm/.pnm, .pam, .bmp, .tga, .tiff/.tif and .ff outputs are encoded (image_out.cpp); .gif, .ico, .pgm, .pbm are not.
 #include <sys/ioctl.h>
 #include <unistd.h>
 

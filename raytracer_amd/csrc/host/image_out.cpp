@@ -1,8 +1,9 @@
 // Output image encoders, chosen by file extension like image 0.23's ImageBuffer::save
 // (reference src/main.rs:161-162): .png (zlib deflate), .jpg / .jpeg (baseline JFIF, quality 75 - the
-// image crate's default; its covers are .jpg), .ppm / .pnm (binary P6), .bmp (24-bit).
-// Other formats the image crate knows (.gif, .tiff, ...) are not encoded here: the call fails with
-// a clear message instead of writing something else under that name.
+// image crate's default; its covers are .jpg), .ppm / .pnm (binary P6), .pam (P7), .bmp (24-bit), .tga (type 2),
+// .tiff / .tif (one uncompressed strip), .ff / .farbfeld.  The formats the image crate knows that need a palette
+// or a container of sizes (.gif, .ico) and the grey / bitmap PNM kinds (.pgm, .pbm) are not encoded here: the call
+// fails with a clear message instead of writing something else under that name.
 #include <zlib.h>
 
 #include <algorithm>
@@ -80,6 +81,80 @@ std::vector<uint8_t> encode_bmp(uint32_t w, uint32_t h, const uint8_t* rgb) {
         uint8_t* dst = &out[54 + (size_t)y * stride];
         for (uint32_t x = 0; x < w; x++) { dst[3 * x] = src[3 * x + 2]; dst[3 * x + 1] = src[3 * x + 1]; dst[3 * x + 2] = src[3 * x]; }
     }
+    return out;
+}
+
+// Truevision TGA, type 2 (uncompressed true colour), 24 bits, top-left origin, BGR.
+std::vector<uint8_t> encode_tga(uint32_t w, uint32_t h, const uint8_t* rgb) {
+    if (w > 65535 || h > 65535) throw std::runtime_error("a .tga image holds at most 65535 x 65535 pixels");
+    std::vector<uint8_t> out(18 + (size_t)w * h * 3, 0);
+    out[2] = 2;
+    out[12] = (uint8_t)w; out[13] = (uint8_t)(w >> 8);
+    out[14] = (uint8_t)h; out[15] = (uint8_t)(h >> 8);
+    out[16] = 24;
+    out[17] = 0x20;  // rows run top-down
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        out[18 + 3 * i] = rgb[3 * i + 2]; out[18 + 3 * i + 1] = rgb[3 * i + 1]; out[18 + 3 * i + 2] = rgb[3 * i];
+    }
+    return out;
+}
+
+// farbfeld: "farbfeld", width and height as big-endian u32, then 16-bit big-endian RGBA (an 8-bit value v becomes v * 257).
+std::vector<uint8_t> encode_farbfeld(uint32_t w, uint32_t h, const uint8_t* rgb) {
+    std::vector<uint8_t> out;
+    out.reserve(16 + (size_t)w * h * 8);
+    const char* magic = "farbfeld";
+    out.insert(out.end(), magic, magic + 8);
+    be32(out, w);
+    be32(out, h);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        for (int c = 0; c < 3; c++) { out.push_back(rgb[3 * i + c]); out.push_back(rgb[3 * i + c]); }
+        out.push_back(0xff); out.push_back(0xff);
+    }
+    return out;
+}
+
+// PAM (P7), RGB, one byte a sample.
+std::vector<uint8_t> encode_pam(uint32_t w, uint32_t h, const uint8_t* rgb) {
+    std::string head = "P7\nWIDTH " + std::to_string(w) + "\nHEIGHT " + std::to_string(h) + "\nDEPTH 3\nMAXVAL 255\nTUPLTYPE RGB\nENDHDR\n";
+    std::vector<uint8_t> out(head.begin(), head.end());
+    out.insert(out.end(), rgb, rgb + (size_t)w * h * 3);
+    return out;
+}
+
+// Baseline TIFF 6.0, little-endian, one uncompressed RGB strip.
+std::vector<uint8_t> encode_tiff(uint32_t w, uint32_t h, const uint8_t* rgb) {
+    const uint64_t pixels = (uint64_t)w * h * 3;
+    if (pixels > 0xfff00000ull) throw std::runtime_error("the image is too large for a .tiff file (4 GB)");
+    const uint32_t n_entries = 10, data_at = 8, bits_at = data_at + (uint32_t)pixels + ((uint32_t)pixels & 1u),
+                   ifd_at = bits_at + 6 + 2;  // (three shorts, padded to a word boundary)
+    std::vector<uint8_t> out((size_t)ifd_at + 2 + n_entries * 12 + 4, 0);
+    auto le16 = [&](size_t at, uint32_t v) { out[at] = (uint8_t)v; out[at + 1] = (uint8_t)(v >> 8); };
+    auto le32 = [&](size_t at, uint32_t v) { le16(at, v & 0xffffu); le16(at + 2, v >> 16); };
+    out[0] = 'I'; out[1] = 'I';
+    le16(2, 42);
+    le32(4, ifd_at);
+    std::memcpy(&out[data_at], rgb, (size_t)pixels);
+    le16(bits_at, 8); le16(bits_at + 2, 8); le16(bits_at + 4, 8);
+    size_t at = ifd_at;
+    le16(at, n_entries);
+    at += 2;
+    auto entry = [&](uint32_t tag, uint32_t type, uint32_t count, uint32_t value) {  // type 3 = SHORT, 4 = LONG
+        le16(at, tag); le16(at + 2, type); le32(at + 4, count);
+        if (type == 3 && count == 1) le16(at + 8, value); else le32(at + 8, value);
+        at += 12;
+    };
+    entry(256, 4, 1, w);              // ImageWidth
+    entry(257, 4, 1, h);              // ImageLength
+    entry(258, 3, 3, bits_at);        // BitsPerSample -> 8, 8, 8
+    entry(259, 3, 1, 1);              // Compression: none
+    entry(262, 3, 1, 2);              // PhotometricInterpretation: RGB
+    entry(273, 4, 1, data_at);        // StripOffsets
+    entry(277, 3, 1, 3);              // SamplesPerPixel
+    entry(278, 4, 1, h);              // RowsPerStrip
+    entry(279, 4, 1, (uint32_t)pixels);  // StripByteCounts
+    entry(284, 3, 1, 1);              // PlanarConfiguration: chunky
+    le32(at, 0);                      // no further IFD
     return out;
 }
 
@@ -279,9 +354,13 @@ void save_image(const std::string& path, uint32_t width, uint32_t height, const 
     else if (ext == "ppm" || ext == "pnm") write_all(path, encode_ppm(width, height, rgb));
     else if (ext == "bmp") write_all(path, encode_bmp(width, height, rgb));
     else if (ext == "jpg" || ext == "jpeg") write_all(path, encode_jpeg(width, height, rgb, 75));
+    else if (ext == "tga") write_all(path, encode_tga(width, height, rgb));
+    else if (ext == "tiff" || ext == "tif") write_all(path, encode_tiff(width, height, rgb));
+    else if (ext == "ff" || ext == "farbfeld") write_all(path, encode_farbfeld(width, height, rgb));
+    else if (ext == "pam") write_all(path, encode_pam(width, height, rgb));
     else
         throw std::runtime_error("The image format could not be determined or is not supported by this build (." + ext +
-                                 "): use .png, .jpg, .ppm or .bmp");
+                                 "): use .png, .jpg, .ppm, .pam, .bmp, .tga, .tiff or .ff");
 }
 
 }  // namespace rt

@@ -147,6 +147,32 @@ def test_save_png_ppm_bmp(in_tmp):
     assert np.array_equal(body[::-1, :, ::-1], img)
 
 
+def test_save_tga_tiff_farbfeld_pam(in_tmp):
+    from PIL import Image
+
+    img = _rows(7, 5, 2)
+    rt.save_image("a.tga", img)
+    raw = open("a.tga", "rb").read()
+    assert raw[2] == 2 and struct.unpack("<HHBB", raw[12:18]) == (5, 7, 24, 0x20) and len(raw) == 18 + 5 * 7 * 3
+    assert np.array_equal(np.frombuffer(raw[18:], dtype=np.uint8).reshape(7, 5, 3)[:, :, ::-1], img)
+    assert np.array_equal(np.asarray(Image.open("a.tga").convert("RGB")), img)
+    for name in ("a.tiff", "b.TIF"):
+        rt.save_image(name, img)
+        assert np.array_equal(np.asarray(Image.open(name).convert("RGB")), img)
+    odd = _rows(3, 3, 5)  # 27 bytes of pixels: the tables after them start on a word boundary
+    rt.save_image("odd.tiff", odd)
+    assert np.array_equal(np.asarray(Image.open("odd.tiff").convert("RGB")), odd)
+    rt.save_image("a.ff", img)
+    raw = open("a.ff", "rb").read()
+    assert raw[:8] == b"farbfeld" and struct.unpack(">II", raw[8:16]) == (5, 7)
+    px = np.frombuffer(raw[16:], dtype=">u2").reshape(7, 5, 4)
+    assert np.array_equal(px[:, :, :3], img.astype(np.uint16) * 257) and (px[:, :, 3] == 65535).all()
+    rt.save_image("a.pam", img)
+    assert open("a.pam", "rb").read() == b"P7\nWIDTH 5\nHEIGHT 7\nDEPTH 3\nMAXVAL 255\nTUPLTYPE RGB\nENDHDR\n" + img.tobytes()
+    with pytest.raises(Exception, match="not supported"):
+        rt.save_image("a.gif", img)
+
+
 def _test_picture(h, w):
     y, x = np.mgrid[0:h, 0:w]
     rng = np.random.default_rng(3)
