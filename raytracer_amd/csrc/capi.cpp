@@ -384,6 +384,7 @@ struct Engine : EngineBase {
     DevBuf<rtd::DNode4> nodes4;
     DevBuf<rtd::DNode<T>> nodes_own;  // only kept when the scene is small enough for LDS staging
     DevBuf<rtd::DObject> objects;
+    DevBuf<rtd::DSky<T>> sky;
     DevBuf<rtd::DBlock<T>> blocks;
     DevBuf<rtd::DXform<T>> xforms;
     DevBuf<rtd::DSphere<T>> spheres;
@@ -682,9 +683,15 @@ struct Engine : EngineBase {
         cvt3(S.camera.horizontal, c.horizontal); cvt3(S.camera.vertical, c.vertical);
         cvt3(S.camera.u, c.u); cvt3(S.camera.v, c.v);
         S.camera.lens_radius = (T)c.lens_radius; S.camera.start_time = (T)c.start_time; S.camera.end_time = (T)c.end_time;
-        S.sky.gradient = d.sky.gradient;
-        cvt3(S.sky.colour, d.sky.colour); cvt3(S.sky.unit_dir, d.sky.unit_dir);
-        cvt3(S.sky.colour0, d.sky.colour0); cvt3(S.sky.colour1, d.sky.colour1);
+        {
+            rtd::DSky<T> sky_host;
+            std::memset(&sky_host, 0, sizeof(sky_host));
+            sky_host.gradient = d.sky.gradient;
+            cvt3(sky_host.colour, d.sky.colour); cvt3(sky_host.unit_dir, d.sky.unit_dir);
+            cvt3(sky_host.colour0, d.sky.colour0); cvt3(sky_host.colour1, d.sky.colour1);
+            sky.upload(std::vector<rtd::DSky<T>>(1, sky_host));
+            S.sky = sky.p;
+        }
         // bounding sphere of the world BVH (every box of every tree lies inside it) for far_shift
         S.far_origin = INFINITY;
         S.bound_centre[0] = S.bound_centre[1] = S.bound_centre[2] = (T)0;
@@ -830,7 +837,7 @@ struct Engine : EngineBase {
     static rtd::DQueue<T> queue(const Work<T>& w, int k) {
         T* b = w.qslab[k];
         size_t n = w.capacity;
-        return rtd::DQueue<T>{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, w.qpid[k]};
+        return rtd::DQueue<T>{b, (uint64_t)n, w.qpid[k]};
     }
     static rtd::DHits<T> hits(const Work<T>& w, bool with_ids) {
         T* b = w.hslab;

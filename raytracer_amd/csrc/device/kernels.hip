@@ -1353,16 +1353,16 @@ constexpr uint32_t TILE = RT_TILE;
 template <typename T>
 __device__ __forceinline__ Ray<T> load_ray(const DQueue<T>& q, uint32_t i) {
     Ray<T> r;
-    r.o = mk(q.ox[i], q.oy[i], q.oz[i]);
-    r.d = mk(q.dx[i], q.dy[i], q.dz[i]);
-    r.time = q.time[i];
+    r.o = mk(q.ox()[i], q.oy()[i], q.oz()[i]);
+    r.d = mk(q.dx()[i], q.dy()[i], q.dz()[i]);
+    r.time = q.time()[i];
     return r;
 }
 template <typename T>
 __device__ __forceinline__ void store_ray(const DQueue<T>& q, uint32_t i, const Ray<T>& r) {
-    q.ox[i] = r.o.x; q.oy[i] = r.o.y; q.oz[i] = r.o.z;
-    q.dx[i] = r.d.x; q.dy[i] = r.d.y; q.dz[i] = r.d.z;
-    q.time[i] = r.time;
+    q.ox()[i] = r.o.x; q.oy()[i] = r.o.y; q.oz()[i] = r.o.z;
+    q.dx()[i] = r.d.x; q.dy()[i] = r.d.y; q.dz()[i] = r.d.z;
+    q.time()[i] = r.time;
 }
 
 
@@ -1449,7 +1449,7 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<
     r.d = unit_vector(ld3(c.lower_left_corner) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin) - offset);
     r.time = rng.range(c.start_time, c.end_time);
     store_ray(q, pid, r);
-    q.tr[pid] = (T)1.0; q.tg[pid] = (T)1.0; q.tb[pid] = (T)1.0;
+    q.tr()[pid] = (T)1.0; q.tg()[pid] = (T)1.0; q.tb()[pid] = (T)1.0;
     q.pid[pid] = pid;
 }
 
@@ -1832,12 +1832,13 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
     bool contributes = false;
     if (mf == RT_MISS) {  // sky(ray), src/hitting.rs:29
         V3<T> c;
-        if (S.sky.gradient) {  // src/camera.rs:78-86
-            T gradient_pos = dot(ld3(S.sky.unit_dir), unit_vector(ray.d));
+        const DSky<T>& sky = *S.sky;
+        if (sky.gradient) {  // src/camera.rs:78-86
+            T gradient_pos = dot(ld3(sky.unit_dir), unit_vector(ray.d));
             T g = (T)0.5 * (gradient_pos + (T)1.0);
-            c = (T)1.0 * (((T)1.0 - g) * ld3(S.sky.colour0) + g * ld3(S.sky.colour1));
+            c = (T)1.0 * (((T)1.0 - g) * ld3(sky.colour0) + g * ld3(sky.colour1));
         } else {
-            c = ld3(S.sky.colour);
+            c = ld3(sky.colour);
         }
         add = coeff(thr, c);
         contributes = true;
@@ -1979,7 +1980,7 @@ __device__ __forceinline__ void compact_store(bool alive, uint32_t tile, const R
         if (alive && tile == t_lead) {
             uint32_t o = t_lead * TILE + start + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
             store_ray(qout, o, nr);
-            qout.tr[o] = thr.x; qout.tg[o] = thr.y; qout.tb[o] = thr.z;
+            qout.tr()[o] = thr.x; qout.tg()[o] = thr.y; qout.tb()[o] = thr.z;
             qout.pid[o] = pid;
         }
         todo &= ~same;
@@ -2009,7 +2010,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DScene<T> S, DB
         if (valid) {
             Ray<T> ray = load_ray(qin, i);
             pid = qin.pid[i];
-            thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
+            thr = mk(qin.tr()[i], qin.tg()[i], qin.tb()[i]);
             uint32_t mf = h.mat_front[i];
             T t = 0, u = 0, v = 0;
             V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
@@ -2097,7 +2098,7 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
             if (valid) {
                 const Ray<T> ray = load_ray(qin, i);
                 pid = qin.pid[i];
-                thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
+                thr = mk(qin.tr()[i], qin.tg()[i], qin.tb()[i]);
                 alive = bounce_once(ray, thr, pid, depth0, nr);
             }
             compact_store(alive, tile, nr, thr, pid, qout, tile_counts_out);
@@ -2147,7 +2148,7 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
                     const uint32_t i = slot_of(tile_offsets, n_tiles, chunk_lo + rank, chunk_lo, &tile);
                     ray = load_ray(qin, i);
                     pid = qin.pid[i];
-                    thr = mk(qin.tr[i], qin.tg[i], qin.tb[i]);
+                    thr = mk(qin.tr()[i], qin.tg()[i], qin.tb()[i]);
                     depth = depth0;
                     alive = true;
                     taken++;
@@ -2302,9 +2303,9 @@ __global__ void __launch_bounds__(BLOCK) k_store_rays(DQueue<T> q, uint32_t n, d
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     double* o = rays9 + (uint64_t)i * 9;
-    o[0] = (double)q.ox[i]; o[1] = (double)q.oy[i]; o[2] = (double)q.oz[i];
-    o[3] = (double)q.dx[i]; o[4] = (double)q.dy[i]; o[5] = (double)q.dz[i];
-    o[6] = (double)q.time[i];
+    o[0] = (double)q.ox()[i]; o[1] = (double)q.oy()[i]; o[2] = (double)q.oz()[i];
+    o[3] = (double)q.dx()[i]; o[4] = (double)q.dy()[i]; o[5] = (double)q.dz()[i];
+    o[6] = (double)q.time()[i];
     o[7] = 0.001;
     o[8] = (double)Lim<double>::inf();
 }

@@ -169,7 +169,9 @@ struct DScene {
     float far_origin;
     T bound_centre[3], bound_radius;
     DCamera<T> camera;
-    DSky<T> sky;
+    // The sky's colours are read where a ray misses, through this pointer to a device copy: as kernel arguments the 25
+    // words were fetched at every kernel's entry and kept in spilled SGPRs by kernels whose rays rarely miss.
+    const DSky<T>* sky;
 };
 
 // Small scenes: one contiguous copy of nodes (own-box form) | objects | xforms | spheres | moving_spheres | rects |
@@ -185,9 +187,29 @@ struct DSmallScene {
 // Ray / path queue: one SoA slab of `capacity` entries per field (coalesced per field).
 template <typename T>
 struct DQueue {
-    T *ox, *oy, *oz, *dx, *dy, *dz, *time;  // Ray (src/math.rs:201-205)
-    T *tr, *tg, *tb;                        // path throughput (product of attenuations)
-    uint32_t* pid;                          // path index inside the batch
+    // Field k of entry i is slab[k * cap + i]: one pointer and one stride as kernel arguments instead of ten pointers
+    // (the lean k_bounce restored its 22 queue pointers from spilled SGPRs with ~190 v_readlane per wave and bounce).
+    T* slab;
+    uint64_t cap;
+    uint32_t* pid;  // path index inside the batch
+#ifdef __HIPCC__
+    // (the empty asm keeps the compiler from computing all ten field pointers of both queues at the kernel's entry and
+    // holding them in spilled SGPRs: a field's address is two scalar instructions where it is used)
+    __device__ __forceinline__ T* field(uint64_t k) const {
+        uint64_t stride = cap;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(stride));
+#endif
+        return slab + k * stride;
+    }
+#define RT_QUEUE_FIELD(name, k) __device__ __forceinline__ T* name() const { return field(k); }
+#else
+#define RT_QUEUE_FIELD(name, k) T* name() const { return slab + (k) * cap; }
+#endif
+    RT_QUEUE_FIELD(ox, 0) RT_QUEUE_FIELD(oy, 1) RT_QUEUE_FIELD(oz, 2)  // Ray (src/math.rs:201-205)
+    RT_QUEUE_FIELD(dx, 3) RT_QUEUE_FIELD(dy, 4) RT_QUEUE_FIELD(dz, 5) RT_QUEUE_FIELD(time, 6)
+    RT_QUEUE_FIELD(tr, 7) RT_QUEUE_FIELD(tg, 8) RT_QUEUE_FIELD(tb, 9)  // path throughput (product of attenuations)
+#undef RT_QUEUE_FIELD
 };
 
 // Hit records written by extend, read by shade (HitRecord, src/hitting.rs:33-41).
