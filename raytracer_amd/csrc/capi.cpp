@@ -842,7 +842,7 @@ struct Engine : EngineBase {
     static rtd::DHits<T> hits(const Work<T>& w, bool with_ids) {
         T* b = w.hslab;
         size_t n = w.capacity;
-        rtd::DHits<T> h{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, w.hmat, nullptr, nullptr, nullptr};
+        rtd::DHits<T> h{b, (uint64_t)n, w.hmat, nullptr, nullptr, nullptr};
         if (with_ids) {
             h.owner = w.hids;
             h.sub = w.hids + n;

@@ -1529,10 +1529,10 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
         if (closest_hit<T, MODE>(S, r, min_dist, max_dist, st, path, depth, &t, &w)) {
 #endif
             Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(S, r, t, w, S.needs_uv != 0 || h.owner != nullptr);
-            h.t[i] = t;
-            h.nx[i] = sf.normal.x; h.ny[i] = sf.normal.y; h.nz[i] = sf.normal.z;
+            h.t()[i] = t;
+            h.nx()[i] = sf.normal.x; h.ny()[i] = sf.normal.y; h.nz()[i] = sf.normal.z;
             if (S.needs_uv != 0 || h.owner != nullptr) {  // nobody reads (u, v) otherwise: 16 B per hit not written, not read
-                h.u[i] = sf.u; h.v[i] = sf.v;
+                h.u()[i] = sf.u; h.v()[i] = sf.v;
             }
             h.mat_front[i] = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
             if (h.owner) {
@@ -1720,10 +1720,10 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend_refill(DScene
                 const uint32_t i = slot;
                 if (have) {
                     Surface<T> sf = make_surface<T, FEAT>(S, walk.ray, best_t, best, S.needs_uv != 0 || h.owner != nullptr);
-                    h.t[i] = best_t;
-                    h.nx[i] = sf.normal.x; h.ny[i] = sf.normal.y; h.nz[i] = sf.normal.z;
+                    h.t()[i] = best_t;
+                    h.nx()[i] = sf.normal.x; h.ny()[i] = sf.normal.y; h.nz()[i] = sf.normal.z;
                     if (S.needs_uv != 0 || h.owner != nullptr) {
-                        h.u[i] = sf.u; h.v[i] = sf.v;
+                        h.u()[i] = sf.u; h.v()[i] = sf.v;
                     }
                     h.mat_front[i] = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
                     if (h.owner) {
@@ -2015,11 +2015,11 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DScene<T> S, DB
             T t = 0, u = 0, v = 0;
             V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
             if (mf != RT_MISS) {
-                t = h.t[i];
+                t = h.t()[i];
                 if (S.needs_uv) {
-                    u = h.u[i]; v = h.v[i];
+                    u = h.u()[i]; v = h.v()[i];
                 }
-                n = mk(h.nx[i], h.ny[i], h.nz[i]);
+                n = mk(h.nx()[i], h.ny()[i], h.nz()[i]);
             }
 #if defined(RT_EXP) && (RT_EXP & 2048)  // timing experiment only: what k_shade costs with no shading in it (its memory floor)
             alive = mf != RT_MISS && depth + 1 < max_bounces;
@@ -2284,7 +2284,7 @@ __global__ void __launch_bounds__(BLOCK) k_store_hits(DQueue<T> q, DHits<T> h, u
         o.t = 0; o.p[0] = o.p[1] = o.p[2] = 0; o.n[0] = o.n[1] = o.n[2] = 0; o.u = o.v = 0;
     } else {
         Ray<T> r = load_ray(q, i);
-        T t = h.t[i];
+        T t = h.t()[i];
         V3<T> p = r.at(t);
         o.hit = 1;
         o.owner = h.owner[i]; o.sub = h.sub[i]; o.world_index = h.world_index[i];
@@ -2292,8 +2292,8 @@ __global__ void __launch_bounds__(BLOCK) k_store_hits(DQueue<T> q, DHits<T> h, u
         o.material = (int32_t)(mf & 0x7fffffffu);
         o.t = (double)t;
         o.p[0] = (double)p.x; o.p[1] = (double)p.y; o.p[2] = (double)p.z;
-        o.n[0] = (double)h.nx[i]; o.n[1] = (double)h.ny[i]; o.n[2] = (double)h.nz[i];
-        o.u = (double)h.u[i]; o.v = (double)h.v[i];
+        o.n[0] = (double)h.nx()[i]; o.n[1] = (double)h.ny()[i]; o.n[2] = (double)h.nz()[i];
+        o.u = (double)h.u()[i]; o.v = (double)h.v()[i];
     }
     out[i] = o;
 }

@@ -215,7 +215,23 @@ struct DQueue {
 // Hit records written by extend, read by shade (HitRecord, src/hitting.rs:33-41).
 template <typename T>
 struct DHits {
-    T *t, *nx, *ny, *nz, *u, *v;
+    T* slab;  // t, nx, ny, nz, u, v: field k of entry i is slab[k * cap + i] (as DQueue)
+    uint64_t cap;
+#ifdef __HIPCC__
+    __device__ __forceinline__ T* field(uint64_t k) const {
+        uint64_t stride = cap;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(stride));
+#endif
+        return slab + k * stride;
+    }
+    __device__ __forceinline__ T* t() const { return field(0); }
+    __device__ __forceinline__ T* nx() const { return field(1); }
+    __device__ __forceinline__ T* ny() const { return field(2); }
+    __device__ __forceinline__ T* nz() const { return field(3); }
+    __device__ __forceinline__ T* u() const { return field(4); }
+    __device__ __forceinline__ T* v() const { return field(5); }
+#endif
     uint32_t* mat_front;                    // material | front_face << 31; RT_MISS for a miss
     int32_t *owner, *sub, *world_index;     // only written when non-null (rt_trace)
 };
