@@ -2,8 +2,12 @@
 #include "flatten.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <future>
 #include <limits>
 #include <map>
 
@@ -334,10 +338,35 @@ private:
     // ---- BVHNode::from_vec (src/hitting.rs:148-197) over boxed items [lo, hi).
     // Axis: the reference draws it at random (:158); here it is the longest axis of the
     // union of the items' boxes, ties to the lower axis (the oracle uses the same rule).
+    // A tree over m items has 2m - 1 nodes, laid out in pre-order (a node, its left subtree, its right subtree): the
+    // place of every node is known before it is built, so large subtrees are built as tasks into the one array, and
+    // the result does not depend on how many run at a time.
     int32_t leaf_base_ = -1;
     int32_t build_bvh(std::vector<BuildItem>& items, size_t lo, size_t hi, int leaf_kind, int* depth, Box* box_out) {
-        int32_t idx = (int32_t)out_.nodes.size();
-        out_.nodes.emplace_back();
+        const int32_t root = (int32_t)out_.nodes.size();
+        out_.nodes.resize(out_.nodes.size() + 2 * (hi - lo) - 1);
+        build_bvh_at(items, lo, hi, leaf_kind, root, depth, box_out, hi - lo >= 65536 ? 4 : 0);
+        return root;
+    }
+    // Sorts items[lo, hi) by sort_box.lo[axis], equal keys in their present order (the reference's sort_by is stable,
+    // src/hitting.rs:166): large ranges through (key, position) pairs, so that the records move once.
+    static void sort_items(std::vector<BuildItem>& items, size_t lo, size_t hi, int axis) {
+        const size_t m = hi - lo;
+        if (m < 2048) {
+            std::stable_sort(items.begin() + (long)lo, items.begin() + (long)hi,
+                             [axis](const BuildItem& a, const BuildItem& b) { return a.sort_box.lo[axis] < b.sort_box.lo[axis]; });
+            return;
+        }
+        std::vector<std::pair<double, uint32_t>> keys(m);
+        for (size_t i = 0; i < m; i++) keys[i] = {items[lo + i].sort_box.lo[axis], (uint32_t)i};
+        std::stable_sort(keys.begin(), keys.end(),
+                         [](const std::pair<double, uint32_t>& a, const std::pair<double, uint32_t>& b) { return a.first < b.first; });
+        std::vector<BuildItem> moved(m);
+        for (size_t i = 0; i < m; i++) moved[i] = items[lo + keys[i].second];
+        std::copy(moved.begin(), moved.end(), items.begin() + (long)lo);
+    }
+    void build_bvh_at(std::vector<BuildItem>& items, size_t lo, size_t hi, int leaf_kind, int32_t idx, int* depth, Box* box_out,
+                      int par_depth) {
         if (hi - lo == 1) {
             rt_node n;
             std::memset(&n, 0, sizeof(n));
@@ -350,7 +379,7 @@ private:
             out_.nodes[(size_t)idx] = n;
             if (box_out) *box_out = items[lo].node_box;
             *depth = 1;
-            return idx;
+            return;
         }
         Box all = items[lo].node_box;
         for (size_t i = lo; i < hi; i++) all = surrounding(all, items[i].node_box);
@@ -363,13 +392,19 @@ private:
                 axis = a;
             }
         }
-        std::stable_sort(items.begin() + (long)lo, items.begin() + (long)hi,
-                         [axis](const BuildItem& a, const BuildItem& b) { return a.sort_box.lo[axis] < b.sort_box.lo[axis]; });
+        sort_items(items, lo, hi, axis);
         size_t halfway = lo + (hi - lo) / 2;
         int dl = 0, dr = 0;
         Box bl, br;
-        int32_t left = build_bvh(items, lo, halfway, leaf_kind, &dl, &bl);
-        int32_t right = build_bvh(items, halfway, hi, leaf_kind, &dr, &br);
+        const int32_t left = idx + 1, right = idx + (int32_t)(2 * (halfway - lo));
+        if (par_depth > 0 && hi - lo >= 32768) {
+            auto task = std::async(std::launch::async, [&] { build_bvh_at(items, lo, halfway, leaf_kind, left, &dl, &bl, par_depth - 1); });
+            build_bvh_at(items, halfway, hi, leaf_kind, right, &dr, &br, par_depth - 1);
+            task.get();
+        } else {
+            build_bvh_at(items, lo, halfway, leaf_kind, left, &dl, &bl, 0);
+            build_bvh_at(items, halfway, hi, leaf_kind, right, &dr, &br, 0);
+        }
         Box nb = surrounding(bl, br);
         rt_node n;
         store(n.lo, nb.lo);
@@ -379,7 +414,6 @@ private:
         out_.nodes[(size_t)idx] = n;
         if (box_out) *box_out = nb;
         *depth = 1 + std::max(dl, dr);
-        return idx;
     }
 
     int32_t add_xform(const Xf& x) {
@@ -516,14 +550,32 @@ private:
                     }
                     int d = 0;
                     leaf_base_ = (int32_t)out_.triangles.size();
+                    const auto t_build = std::chrono::steady_clock::now();
                     blas_root_[(size_t)oi] = build_bvh(items, 0, items.size(), RT_LEAF_TRIANGLE, &d, nullptr);
+                    if (std::getenv("RT_DEBUG"))
+                        std::fprintf(stderr, "mesh BVH of %zu triangles: %.1f ms\n", items.size(),
+                                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count());
                     leaf_base_ = -1;
                     blas_depth_[(size_t)oi] = d;
-                    for (const BuildItem& it : items) {
-                        const MeshTriangle& t = md.triangles[(size_t)it.payload];
-                        V3 n = v3(t.normal);
-                        out_.triangles.push_back(make_triangle(v3(t.p[0]), v3(t.p[1]), v3(t.p[2]),
-                                                               t.has_normal ? &n : nullptr, o.material, oi, it.payload));
+                    const size_t first = out_.triangles.size();
+                    out_.triangles.resize(first + items.size());
+                    auto make_range = [&](size_t a, size_t b) {
+                        for (size_t k = a; k < b; k++) {
+                            const BuildItem& it = items[k];
+                            const MeshTriangle& t = md.triangles[(size_t)it.payload];
+                            V3 n = v3(t.normal);
+                            out_.triangles[first + k] = make_triangle(v3(t.p[0]), v3(t.p[1]), v3(t.p[2]),
+                                                                      t.has_normal ? &n : nullptr, o.material, oi, it.payload);
+                        }
+                    };
+                    if (items.size() >= 65536) {  // slices as tasks (every record is written by one of them)
+                        const size_t slices = 8, per = (items.size() + slices - 1) / slices;
+                        std::vector<std::future<void>> tasks;
+                        for (size_t a = 0; a < items.size(); a += per)
+                            tasks.push_back(std::async(std::launch::async, make_range, a, std::min(items.size(), a + per)));
+                        for (auto& t : tasks) t.get();
+                    } else {
+                        make_range(0, items.size());
                     }
                 }
                 r.kind = RT_OBJ_BLAS;

@@ -42,7 +42,8 @@ MeshData parse_obj_mesh(const std::string& text, const std::string& object_name,
         return objects.back();
     };
     std::istringstream in(text);
-    std::string line;
+    std::string line, tok;
+    std::vector<Corner> cs;
     int lineno = 0;
     auto fail = [&](const std::string& msg) {
         throw SceneError(path + ":" + std::to_string(lineno) + ": " + msg);
@@ -60,51 +61,71 @@ MeshData parse_obj_mesh(const std::string& text, const std::string& object_name,
         }
         size_t hash = line.find('#');
         if (hash != std::string::npos) line.erase(hash);
-        std::istringstream ls(line);
-        std::string tag;
-        if (!(ls >> tag)) continue;
-        if (tag == "o") {
+        // (scanned in place: a stream per line costs 2 s on a million-triangle file)
+        const char* p = line.c_str();
+        auto skip_space = [&] { while (*p == ' ' || *p == '\t' || *p == '\v' || *p == '\f' || *p == '\r') p++; };
+        auto token_end = [](const char* q) { while (*q && *q != ' ' && *q != '\t' && *q != '\v' && *q != '\f' && *q != '\r') q++; return q; };
+        skip_space();
+        const char* tag_end = token_end(p);
+        if (tag_end == p) continue;
+        const size_t tag_len = (size_t)(tag_end - p);
+        auto tag_is = [&](const char* t) { return std::strlen(t) == tag_len && std::memcmp(p, t, tag_len) == 0; };
+        const bool is_o = tag_is("o"), is_v = tag_is("v"), is_vn = tag_is("vn"), is_f = tag_is("f");
+        p = tag_end;
+        auto three_numbers = [&](double* out) {
+            for (int k = 0; k < 3; k++) {
+                char* end = nullptr;
+                out[k] = std::strtod(p, &end);
+                if (end == p) return false;
+                p = end;
+            }
+            return true;
+        };
+        if (is_o) {
             ObjObject o;
-            std::string rest;
-            std::getline(ls, rest);
+            std::string rest(p);
             size_t a = rest.find_first_not_of(" \t");
             size_t b = rest.find_last_not_of(" \t");
             o.name = a == std::string::npos ? "" : rest.substr(a, b - a + 1);
             o.v_min = v.size() / 3;
             o.vn_min = vn.size() / 3;
             objects.push_back(std::move(o));
-        } else if (tag == "v") {
-            double x, y, z;
-            if (!(ls >> x >> y >> z)) fail("bad vertex");
-            v.push_back(x); v.push_back(y); v.push_back(z);
+        } else if (is_v) {
+            double xyz[3];
+            if (!three_numbers(xyz)) fail("bad vertex");
+            v.insert(v.end(), xyz, xyz + 3);
             current().v_count++;
-        } else if (tag == "vn") {
-            double x, y, z;
-            if (!(ls >> x >> y >> z)) fail("bad normal");
-            vn.push_back(x); vn.push_back(y); vn.push_back(z);
+        } else if (is_vn) {
+            double xyz[3];
+            if (!three_numbers(xyz)) fail("bad normal");
+            vn.insert(vn.end(), xyz, xyz + 3);
             current().vn_count++;
-        } else if (tag == "f") {
+        } else if (is_f) {
             ObjObject& o = current();
-            std::vector<Corner> cs;
-            std::string tok;
-            while (ls >> tok) {
+            cs.clear();
+            for (;;) {
+                skip_space();
+                const char* q = token_end(p);
+                if (q == p) break;
+                tok.assign(p, (size_t)(q - p));  // (a copy, so that a number never runs on into the next token)
+                p = q;
                 Corner c;
                 // v, v/vt, v//vn, v/vt/vn
-                const char* p = tok.c_str();
+                const char* tp = tok.c_str();
                 char* end = nullptr;
-                c.v = std::strtol(p, &end, 10);
-                if (end == p) fail("bad face index `" + tok + "`");
+                c.v = std::strtol(tp, &end, 10);
+                if (end == tp) fail("bad face index `" + tok + "`");
                 if (*end == '/') {
-                    p = end + 1;
-                    if (*p != '/') {
-                        (void)std::strtol(p, &end, 10);  // vt, unused
+                    tp = end + 1;
+                    if (*tp != '/') {
+                        (void)std::strtol(tp, &end, 10);  // vt, unused
                     } else {
-                        end = const_cast<char*>(p);
+                        end = const_cast<char*>(tp);
                     }
                     if (*end == '/') {
-                        p = end + 1;
-                        long n = std::strtol(p, &end, 10);
-                        if (end != p) {
+                        tp = end + 1;
+                        long n = std::strtol(tp, &end, 10);
+                        if (end != tp) {
                             c.has_n = true;
                             c.n = n;
                         }
