@@ -1030,6 +1030,93 @@ template <int MODE> struct WalkFeat {
                                                              : FEAT_ALL;
 };
 
+// The four-wide WORLD tree walked by a group of lanes that hold the same ray (worlds without meshes: a leaf is an
+// object test that needs no stack): blas_hit4_group's frontier, with object_hit at the leaves and the objects'
+// depth-first ranks for exact ties, as in the one-lane loop of closest_hit.  false: the frontier has too little
+// room (the caller walks with one lane).
+template <typename T, int FEAT, typename ST>
+__device__ bool world_hit4_group(const DScene<T>& S, const Ray<T>& ray, T min_dist, T max_dist, ST st, float shift, PathRef path,
+                                 uint32_t depth, bool* found_out, T* t_out, Winner* w_out) {
+    const int G = st.group;
+    const int lane = threadIdx.x & 63, gl = lane & (G - 1);
+    const uint64_t gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane - gl);
+    const uint64_t below = gmask & ((1ull << lane) - 1ull);
+    const int fcap = st.cap * G;
+    const int reserve = S.coop_reserve;
+    if (fcap < 2 * reserve + 4 * G) return false;
+    auto slot = [&](int e) -> int32_t* { return st.base + (e / G) * st.stride + ((e & (G - 1)) - gl); };
+    const RayF f = ray_f32(ray, shift);
+    const float tmin32 = round_down(min_dist - (T)shift);
+    float bound32 = round_up(max_dist - (T)shift);
+    const float MISS = __int_as_float(0x7f800000);
+    int count = 1;
+    if (gl == 0) *slot(0) = S.tlas_root4;
+    bool found = false;
+    int32_t best_rank = -1;
+    Winner best{-1, -1};
+    while (count > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int n = count < G ? count : G;
+        if (count + 3 * n > fcap - reserve) n = 1;
+        const bool active = gl < n;
+        const int32_t ref = active ? *slot(count - n + gl) : RT_EMPTY;
+        count -= n;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int32_t c[4] = {RT_EMPTY, RT_EMPTY, RT_EMPTY, RT_EMPTY};
+        float key[4] = {MISS, MISS, MISS, MISS};
+        T t = max_dist;
+        int32_t rank = -1;
+        Winner w{-1, -1};
+        bool hit = false;
+        if (ref >= 0) {
+            const Node4Regs nd = load_node4(S.nodes4, ref);
+            float near[4], far[4];
+            node4_boxes(nd, f, tmin32, bound32, near, far);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                c[k] = nd.child(k);
+                key[k] = ((c[k] != RT_EMPTY) & (far[k] >= near[k])) ? near[k] : MISS;
+            }
+        } else if (ref != RT_EMPTY) {
+            const int oi = -1 - ref;
+            T th;
+            int prim;
+            if (object_hit<T, false, FEAT>(S, oi, ray, min_dist, max_dist, st, st.cap, shift, path, depth, &th, &prim)) {
+                hit = true;
+                t = th;
+                rank = S.objects[oi].dfs_rank;
+                w = Winner{oi, prim};
+            }
+        }
+        for (uint64_t hits = __ballot(hit) & gmask; hits; hits &= hits - 1) {
+            const int from = __ffsll((long long)hits) - 1;
+            const T o_t = __shfl(t, from);
+            const int32_t o_rank = __shfl(rank, from);
+            const int o_obj = __shfl(w.obj, from), o_prim = __shfl(w.prim, from);
+            if (o_t <= max_dist && (!found || o_t < max_dist || o_rank > best_rank)) {
+                max_dist = o_t;
+                bound32 = round_up(o_t - (T)shift);
+                best = Winner{o_obj, o_prim};
+                best_rank = o_rank;
+                found = true;
+            }
+        }
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const bool push = key[k] < MISS && key[k] <= bound32;
+            const uint64_t m = __ballot(push) & gmask;
+            if (push) *slot(count + __popcll(m & below)) = c[k];
+            count += __popcll(m);
+        }
+    }
+    *found_out = found;
+    *t_out = max_dist;
+    *w_out = best;
+    return true;
+}
+
 template <typename T, int MODE, typename ST>
 __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T max_dist, ST st, PathRef path,
                             uint32_t depth, T* t_out, Winner* w_out) {
@@ -1115,6 +1202,10 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
             }
             t = bound;
         } else {
+            bool grouped = false;
+            if constexpr (ST::COOP && walks_node4(MODE) && (FEAT & FEAT_BLAS) == 0)
+                grouped = world_hit4_group<T, FEAT>(S, ray, min_dist, max_dist, st, shift, path, depth, &found, &t, &w);
+            if (!grouped) {
             const RayF f = ray_f32(ray, shift);
             const float tmin32 = round_down(min_dist - (T)shift);
             T bound = max_dist;
@@ -1173,6 +1264,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
             }
             RT_PROF_FLUSH;
             t = bound;
+            }
         }
         if (found && (!have || t < best_t)) {
             best_t = t;
@@ -2111,7 +2203,7 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
         // lane whose path has ended takes the next one of the share, so the waves stay full until the queue is
         // empty, and the launch ends as long after that as its longest path.
         uint32_t extra_queries = 0, deepest = depth0, taken = 0;
-        constexpr bool COOP_MODE = MODE == WALK_NODE2_MESH4 || MODE == WALK_NODE4_MESH;
+        constexpr bool COOP_MODE = walks_node4(MODE);  // (meshes: the mesh walk is shared out; without: the world walk)
         const uint32_t CHUNK = max(64u, min(1024u, (total / (gridDim.x * (BLOCK / 64) * 8u)) & ~63u));
         uint32_t chunk_lo = 0, chunk_hi = 0;  // (wave-uniform) what is left of the wave's share
         bool exhausted = false;               // (wave-uniform)

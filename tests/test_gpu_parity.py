@@ -286,6 +286,9 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_TAIL": "0"}),
         ("blocks_ball", {"RT_TAIL": "0"}),
         ("blue_ball", {"RT_TAIL": "1000000000"}),              # the whole render after bounce 4 in the tail launch
+        ("blocks_ball", {"RT_COOP": "0"}),                     # world tree without meshes: the world walk is what the groups share
+        ("blocks_ball", {"RT_COOP": "32"}),
+        ("blocks_ball", {"RT_COOP": "32", "RT_FEATURES": "all"}),
         ("knight", {"RT_COOP": "0"}),                          # one lane per path to the end of the tail launch (no lane groups)
         ("knight", {"RT_COOP": "32"}),                         # groups of two lanes and up
         ("knight", {"RT_COOP": "32", "RT_FEATURES": "all"}),
