@@ -20,12 +20,12 @@ for name in ["two_spheres", "cornell", "globe", "blocks_ball", "knight", "blue_b
     r = rt.Renderer(0)
     r.upload(sc)
     o = orc.OracleScene.load(path, ROOT)
-    W = 72
+    W = int(sys.argv[1]) if len(sys.argv) > 1 else 72
     H = sc.image_height(W)
-    spp, mb = 16, 50
+    spp, mb = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 50
     _, sums, st = r.render_rows(W, H, 0, H, spp, mb, seed=2024)
-    _, osums, orays = o.render(W, H, 0, H, spp, mb, seed=2024, threads=8)
-    _, osums2, _ = o.render(W, H, 0, H, spp, mb, seed=2025, threads=8)
+    _, osums, orays = o.render(W, H, 0, H, spp, mb, seed=2024, threads=16)
+    _, osums2, _ = o.render(W, H, 0, H, spp, mb, seed=2025, threads=16)
     close = np.isclose(sums, osums, rtol=1e-6, atol=1e-9).all(axis=2)
     dl = np.abs((sums - osums) @ LUM) / spp
     noise = np.abs((osums - osums2) @ LUM) / spp
