@@ -986,12 +986,26 @@ __device__ __noinline__ T medium_log_draw(PathRef path, uint32_t rng_key, uint32
     return log(rng.next());
 }
 
+#ifdef RT_MEDIUM_NOINLINE
+#define RT_MEDIUM_ATTR __noinline__
+#else
+#define RT_MEDIUM_ATTR
+#endif
+template <typename T, bool UNIFORM, int FEAT, typename ST>
+__device__ RT_MEDIUM_ATTR bool medium_hit(const DScene<T>& S, const DObject ob, const Ray<T>& world_ray, T min_dist, T max_dist, ST st,
+                                          int sp, float shift, PathRef path, uint32_t depth, T* t_out, int* prim_out);
 template <typename T, bool UNIFORM, int FEAT, typename ST>
 __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist, ST st,
                            int sp, float shift, PathRef path, uint32_t depth, T* t_out, int* prim_out) {
     const DObject ob = rec<UNIFORM>(&S.objects[oi]);
     if ((FEAT & FEAT_MEDIA) == 0 || ob.kind != RT_OBJ_MEDIUM)
         return simple_object_hit<T, UNIFORM, FEAT>(S, oi, world_ray, min_dist, max_dist, st, sp, shift, t_out, prim_out);
+    return medium_hit<T, UNIFORM, FEAT>(S, ob, world_ray, min_dist, max_dist, st, sp, shift, path, depth, t_out, prim_out);
+}
+// ConstantMedium::hit, src/objects.rs:398-441.
+template <typename T, bool UNIFORM, int FEAT, typename ST>
+__device__ RT_MEDIUM_ATTR bool medium_hit(const DScene<T>& S, const DObject ob, const Ray<T>& world_ray, T min_dist, T max_dist, ST st,
+                                          int sp, float shift, PathRef path, uint32_t depth, T* t_out, int* prim_out) {
     const DMedium<T> md = rec<UNIFORM>(&S.media[ob.first]);
     Ray<T> r = world_ray;
     if (ob.xform >= 0) r = to_object_space(rec<UNIFORM>(&S.xforms[ob.xform]), world_ray);
