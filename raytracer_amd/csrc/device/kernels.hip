@@ -605,7 +605,15 @@ extern "C" void rt_exp_cut_hist(unsigned long long* first, unsigned long long* l
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_first), z, sizeof(g_cut_first));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_left), z, sizeof(g_cut_left));
 }
+__device__ unsigned long long g_mesh_live[65];  // wave-steps of the one-lane mesh walk by the number of lanes still in it
 #define RT_STEP_COUNT g_lane_steps[threadIdx.x]++
+#define RT_MESH_LIVE do { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_mesh_live[__popcll(m_)], 1ull); } while (0)
+extern "C" void rt_exp_mesh_live(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mesh_live), sizeof(g_mesh_live));
+    unsigned long long z[65] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mesh_live), z, sizeof(z));
+}
 extern "C" void rt_exp_step_hist(unsigned long long* hist, unsigned long long* waves) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_step_hist), sizeof(g_step_hist));
@@ -616,6 +624,7 @@ extern "C" void rt_exp_step_hist(unsigned long long* hist, unsigned long long* w
 }
 #else
 #define RT_STEP_COUNT
+#define RT_MESH_LIVE
 #endif
 #if defined(RT_EXP) && (RT_EXP & 32)  // measurement only: lane / wave step counts of the four-wide walks (scripts/exp_steps.py)
 __device__ unsigned long long g_prof[8];
@@ -753,6 +762,7 @@ __device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T 
     for (;;) {
         RT_PROF(0);
         RT_STEP_COUNT;
+        RT_MESH_LIVE;
 #ifdef RT_BVH8
         const Node4Regs n = load_node4(S.nodes4, next), n_hi = load_node4(S.nodes4, next + 1);
         next = node8_step(n, n_hi, f, tmin32, bound32, S.ordered != 0, st, sp);

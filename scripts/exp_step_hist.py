@@ -31,6 +31,9 @@ hist = (C.c_ulonglong * 2048)()
 waves = (C.c_ulonglong * 2)()
 lib.rt_exp_step_hist(hist, waves)
 lib.rt_exp_cut_hist((C.c_ulonglong * 5)(), (C.c_ulonglong * (5 * 2048))())
+mesh_live = (C.c_ulonglong * 65)()
+lib.rt_exp_mesh_live(mesh_live)
+os.environ.setdefault("RT_TAIL", "0")  # every bounce through k_extend: the tail launch would add its own walks to the counts
 r.render_rows(W, H, 0, H, spp, 50, seed=0, want_sums=False)
 lib.rt_exp_step_hist(hist, waves)
 h = np.array(list(hist), dtype=np.int64)
@@ -66,3 +69,11 @@ for c, cut in enumerate((8, 16, 24, 32, 48)):
             again += s2.max(axis=1).mean() * (nleft * frac2 / 64.0)
         line += f"; second pass to the end: total {(total + to_end) / uncut * 100:5.1f} %; three passes (cut at {4 * cut}): {(total + again) / uncut * 100:5.1f} %"
     print(line)
+
+lib.rt_exp_mesh_live(mesh_live)
+ml = np.array(list(mesh_live), dtype=np.int64)
+if ml.sum():
+    print(f"  node steps of the one-lane mesh walk: {ml.sum()} wave-steps, {(ml * np.arange(65)).sum() / ml.sum():.1f} lanes in them on average")
+    c = np.cumsum(ml) / ml.sum()
+    for k in (1, 2, 4, 8, 16, 32):
+        print(f"    with <= {k:2d} lanes still walking: {c[k] * 100:5.1f} % of the wave-steps")
