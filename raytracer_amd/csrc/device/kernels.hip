@@ -605,6 +605,17 @@ extern "C" void rt_exp_cut_hist(unsigned long long* first, unsigned long long* l
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_first), z, sizeof(g_cut_first));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_left), z, sizeof(g_cut_left));
 }
+// steps of every ray of the k_extend launch of one bounce, by its place in the launch (what would regrouping the
+// rays of a block or a tile by their kind buy?)
+__device__ unsigned short g_ray_steps[1 << 23];
+__device__ unsigned int g_ray_steps_depth = 0xffffffffu;
+extern "C" void rt_exp_ray_steps(unsigned short* out, unsigned int n, unsigned int depth_wanted) {
+    (void)hipDeviceSynchronize();
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_steps), (size_t)n * sizeof(unsigned short));
+    void* base = nullptr;
+    if (hipGetSymbolAddress(&base, HIP_SYMBOL(g_ray_steps)) == hipSuccess) (void)hipMemset(base, 0, sizeof(g_ray_steps));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ray_steps_depth), &depth_wanted, sizeof(depth_wanted));
+}
 __device__ unsigned long long g_mesh_live[65];  // wave-steps of the one-lane mesh walk by the number of lanes still in it
 #define RT_STEP_COUNT g_lane_steps[threadIdx.x]++
 #define RT_MESH_LIVE do { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_mesh_live[__popcll(m_)], 1ull); } while (0)
@@ -1628,6 +1639,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
         const bool got = closest_hit<T, MODE>(S, r, min_dist, max_dist, st, path, depth, &t, &w);
         {
             const uint32_t steps = g_lane_steps[threadIdx.x];
+            if (depth == g_ray_steps_depth && d < (1u << 23)) g_ray_steps[d] = (unsigned short)min(steps, 65535u);
             atomicAdd(&g_step_hist[min(steps, 2047u)], 1ull);
             uint32_t longest = steps;
             for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));

@@ -1,0 +1,57 @@
+"""What would regrouping the rays of a k_extend launch buy?  Records the steps (node and leaf visits) of every ray of the
+launch of one bounce by its place in the launch (library built with -DRT_EXP=1024) and sums the longest walk per wave
+for the order as it is, for the rays of each 256-ray block (or 4096-ray tile) split into "walks the mesh" / "does not",
+and for a full sort by length inside the block / tile (the bound of what any regrouping by a predicted length can reach).
+usage: RT_MI355X_LIB=<variant .so> python scripts/exp_regroup.py [scene] [spp]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import torch  # noqa: E402,F401
+
+import raytracer_amd as rt  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "knight"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+if name == "knight":
+    import gen_knight
+
+    gen_knight.ensure(os.path.join(ROOT, "examples", "knight.obj"))
+os.environ["RT_TAIL"] = "0"
+os.environ["RT_LANES"] = "1"
+sc = rt.Scene.load(os.path.join(ROOT, "examples", name + ".json5"), ROOT)
+r = rt.Renderer(0, max_paths=1 << 26)
+r.upload(sc)
+W = 600
+H = sc.image_height(W)
+lib = rt.load_library()
+lib.rt_exp_ray_steps.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+N = 1 << 23
+for depth in (0, 1, 2, 4, 8):
+    lib.rt_exp_ray_steps(None, 0, depth)
+    _, _, st = r.render_rows(W, H, 0, H, spp, 50, seed=0, want_sums=False)
+    buf = np.zeros(N, dtype=np.uint16)
+    lib.rt_exp_ray_steps(buf.ctypes.data, N, 0xffffffff)
+    n = int(np.max(np.nonzero(buf)[0])) + 1 if buf.any() else 0
+    n -= n % 4096
+    if n == 0:
+        continue
+    s = buf[:n].astype(np.int64)
+
+    def cost(order_fn, group):
+        g = s.reshape(-1, group)
+        g = order_fn(g)
+        return g.reshape(-1, 64).max(axis=1).sum()
+
+    base = cost(lambda g: g, 256)
+    line = f"bounce {depth}: {n} rays, {s.mean():.1f} steps per ray; a wave pays {base / (n / 64):.1f} (all lanes busy: {s.sum() / 64 / (n / 64):.1f})"
+    for group in (256, 4096):
+        split = cost(lambda g: np.take_along_axis(g, np.argsort(g > 4, axis=1, kind="stable"), axis=1), group)
+        full = cost(lambda g: np.sort(g, axis=1), group)
+        line += f"; in {group}s: mesh / no mesh {split / base * 100:.0f} %, sorted by length {full / base * 100:.0f} %"
+    print(line)
