@@ -1557,9 +1557,20 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_tiles(const uint32_t* __r
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<T> q, uint32_t n_paths,
                                                    uint32_t* tile_counts) {
-    uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;
-    if (pid >= n_paths) return;
-    if (pid % TILE == 0) tile_counts[pid / TILE] = min(TILE, n_paths - pid);
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;  // place in the queue
+    if (slot >= n_paths) return;
+    if (slot % TILE == 0) tile_counts[slot / TILE] = min(TILE, n_paths - slot);
+    uint32_t pid = slot;
+    if (B.blocked) {  // the slot counts through 8 x 8 blocks of pixels (DBatch::blocked)
+        const uint32_t sl = slot / B.npix, pl = slot - sl * B.npix;
+        const uint32_t W8 = B.width * 8u, strip = pl / W8;
+        uint32_t p = pl;  // (a last strip of fewer than 8 rows: along its rows, as pl counts them)
+        if (8u * strip + 8u <= B.rows) {
+            const uint32_t rem = pl - strip * W8, chunk = rem >> 6, inner = rem & 63u;
+            p = (8u * strip + (inner >> 3)) * B.width + 8u * chunk + (inner & 7u);
+        }
+        pid = sl * B.npix + p;
+    }
     uint32_t pixel, sample;
     path_ids(B, pid, &pixel, &sample);
     uint32_t i = pixel % B.width, j = pixel / B.width;
@@ -1575,9 +1586,9 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<
     r.o = ld3(c.origin) + offset;
     r.d = unit_vector(ld3(c.lower_left_corner) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin) - offset);
     r.time = rng.range(c.start_time, c.end_time);
-    store_ray(q, pid, r);
-    q.tr()[pid] = (T)1.0; q.tg()[pid] = (T)1.0; q.tb()[pid] = (T)1.0;
-    q.pid[pid] = pid;
+    store_ray(q, slot, r);
+    q.tr()[slot] = (T)1.0; q.tg()[slot] = (T)1.0; q.tb()[slot] = (T)1.0;
+    q.pid[slot] = pid;
 }
 
 // Copies a small scene's traversal records into LDS (all threads of the block) and points S at them.

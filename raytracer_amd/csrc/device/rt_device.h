@@ -244,6 +244,13 @@ struct DBatch {      // which pixels / samples the paths of a batch stand for
     uint32_t s0;                       // first sample index of the batch
     uint32_t trace_mode;               // 1: rt_trace - pixel = s0 + pid (global ray index), sample = 0
     uint64_t seed;
+    // blocked != 0 (width % 8 == 0): k_raygen puts the paths of a sample into the queue through 8 x 8 blocks of
+    // pixels (strips of 8 rows, runs of 8 columns; a last strip of fewer rows along its rows) instead of along the
+    // rows: a wave's 64 paths then start in a square of the image, not on a 64-pixel line, and stay neighbours through
+    // the bounces (the queues keep the order).  A path is still named by pid = sample * npix + y * W + x, which the
+    // queue carries: nothing after k_raygen knows of the order.  Measured on the knight's primary rays: 32 % fewer
+    // wave-steps in k_extend (scripts/exp_regroup.py).
+    uint32_t rows, blocked;            // rows = npix / width
 };
 
 // k_bounce as the tail of a batch: with ray_total != nullptr the kernel carries every path of its

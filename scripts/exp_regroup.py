@@ -55,3 +55,12 @@ for depth in (0, 1, 2, 4, 8):
         full = cost(lambda g: np.sort(g, axis=1), group)
         line += f"; in {group}s: mesh / no mesh {split / base * 100:.0f} %, sorted by length {full / base * 100:.0f} %"
     print(line)
+    if depth == 0:
+        # primary rays: a wave is 64 neighbours of a pixel row; what if it were a block of pixels?  (image cropped to 64s)
+        k = n // (W * H)
+        Wc, Hc = W - W % 64, H - H % 64
+        img = s[:k * W * H].reshape(k, H, W)[:, :Hc, :Wc]
+        rows = img.reshape(-1, 64).max(axis=1).sum()
+        for bh, bw in ((8, 8), (4, 16), (16, 4), (2, 32)):
+            blk = img.reshape(k, Hc // bh, bh, Wc // bw, bw).transpose(0, 1, 3, 2, 4).reshape(-1, 64).max(axis=1).sum()
+            print(f"  primary rays in {bh} x {bw} pixel blocks per wave: {blk / rows * 100:.0f} % of the wave-steps of 1 x 64 strips")

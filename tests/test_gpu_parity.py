@@ -286,6 +286,9 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_TAIL": "0"}),
         ("blocks_ball", {"RT_TAIL": "0"}),
         ("blue_ball", {"RT_TAIL": "1000000000"}),              # the whole render after bounce 4 in the tail launch
+        ("cornell", {"RT_PIXEL_BLOCKS": "0"}),                 # paths numbered along the pixel rows, not through 8 x 8 blocks
+        ("knight", {"RT_PIXEL_BLOCKS": "0"}),
+        ("blocks_ball", {"RT_PIXEL_BLOCKS": "0"}),             # 96 x 54: a ragged last strip of 6 rows
         ("blocks_ball", {"RT_COOP": "0"}),                     # world tree without meshes: the world walk is what the groups share
         ("blocks_ball", {"RT_COOP": "32"}),
         ("blocks_ball", {"RT_COOP": "32", "RT_FEATURES": "all"}),
