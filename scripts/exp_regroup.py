@@ -64,3 +64,8 @@ for depth in (0, 1, 2, 4, 8):
         for bh, bw in ((8, 8), (4, 16), (16, 4), (2, 32)):
             blk = img.reshape(k, Hc // bh, bh, Wc // bw, bw).transpose(0, 1, 3, 2, 4).reshape(-1, 64).max(axis=1).sum()
             print(f"  primary rays in {bh} x {bw} pixel blocks per wave: {blk / rows * 100:.0f} % of the wave-steps of 1 x 64 strips")
+        for bh, bw, ns in ((4, 4, 4), (2, 2, 16), (1, 1, 64), (4, 8, 2)):  # ... and several samples of a pixel in one wave
+            if k % ns:
+                continue
+            blk = (img.reshape(k // ns, ns, Hc // bh, bh, Wc // bw, bw).transpose(0, 2, 4, 1, 3, 5).reshape(-1, 64).max(axis=1).sum())
+            print(f"  {bh} x {bw} pixels x {ns} samples per wave: {blk / rows * 100:.0f} %")
