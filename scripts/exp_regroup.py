@@ -17,7 +17,7 @@ import torch  # noqa: E402,F401
 import raytracer_amd as rt  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "knight"
-spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 17
 if name == "knight":
     import gen_knight
 
@@ -65,7 +65,9 @@ for depth in (0, 1, 2, 4, 8):
             blk = img.reshape(k, Hc // bh, bh, Wc // bw, bw).transpose(0, 1, 3, 2, 4).reshape(-1, 64).max(axis=1).sum()
             print(f"  primary rays in {bh} x {bw} pixel blocks per wave: {blk / rows * 100:.0f} % of the wave-steps of 1 x 64 strips")
         for bh, bw, ns in ((4, 4, 4), (2, 2, 16), (1, 1, 64), (4, 8, 2)):  # ... and several samples of a pixel in one wave
-            if k % ns:
+            kk = k - k % ns
+            if kk == 0:
                 continue
-            blk = (img.reshape(k // ns, ns, Hc // bh, bh, Wc // bw, bw).transpose(0, 2, 4, 1, 3, 5).reshape(-1, 64).max(axis=1).sum())
-            print(f"  {bh} x {bw} pixels x {ns} samples per wave: {blk / rows * 100:.0f} %")
+            sub = img[:kk]
+            blk = (sub.reshape(kk // ns, ns, Hc // bh, bh, Wc // bw, bw).transpose(0, 2, 4, 1, 3, 5).reshape(-1, 64).max(axis=1).sum())
+            print(f"  {bh} x {bw} pixels x {ns} samples per wave: {blk / sub.reshape(-1, 64).max(axis=1).sum() * 100:.0f} %")
