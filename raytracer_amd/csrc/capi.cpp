@@ -1019,7 +1019,8 @@ struct Engine : EngineBase {
         // resident at a time; what it saves is the wait for the slowest ray of every bounce.
         uint32_t tail_threshold = fused ? tail_threshold_fused : tail_threshold_tree;
         if (const char* e = std::getenv("RT_TAIL")) tail_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
-        // RT_PIXEL_BLOCKS=0: paths numbered along the pixel rows instead of through 8 x 8 blocks (A/B runs; same image)
+        // RT_PIXEL_BLOCKS=0: paths enter the queue along the pixel rows; =1: through 8 x 8 blocks of pixels, sample by
+        // sample; unset: a wave holds several samples of a few neighbouring pixels (DBatch::blocked; same image always)
         const char* pixel_blocks_env = std::getenv("RT_PIXEL_BLOCKS");
         const bool pixel_blocks = !(pixel_blocks_env && pixel_blocks_env[0] == '0');
         uint32_t runahead = 2;  // bounces enqueued beyond the last one whose live count the host has seen
@@ -1086,6 +1087,7 @@ struct Engine : EngineBase {
                 b.n_paths = (uint32_t)(npix * b.bns);
                 b.n_tiles = tiles_for(b.n_paths);
                 b.B = rtd::DBatch{W, H, j0, (uint32_t)npix, b.bs0, 0u, seed, (uint32_t)(npix / W), pixel_blocks && W % 8 == 0 && S.n_sweep == 0 ? 1u : 0u};  // (tree walks only: a sweep has no lanes to keep in step)
+                if (b.B.blocked && pixel_blocks_env == nullptr) b.B.blocked = 2u;  // pixels x samples per wave
                 b.depth = 0;
                 b.known_depth = 0;
                 b.known_alive = b.n_paths;

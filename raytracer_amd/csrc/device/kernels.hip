@@ -1561,7 +1561,36 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<
     if (slot >= n_paths) return;
     if (slot % TILE == 0) tile_counts[slot / TILE] = min(TILE, n_paths - slot);
     uint32_t pid = slot;
-    if (B.blocked) {  // the slot counts through 8 x 8 blocks of pixels (DBatch::blocked)
+    if (B.blocked == 2u) {
+        // A wave = 64 / n neighbouring pixels x n samples of each, n the largest power of two (<= 64) that the batch's
+        // samples still hold: its samples are taken in runs of 64, then 32, 16, ... as the binary digits of their count
+        // say.  (The width is a multiple of 8; every quotient but one is a shift.)
+        const uint32_t n_samples = n_paths / B.npix, s_slot = slot / B.npix;
+        uint32_t run_first = s_slot & ~63u, run = 64u;  // the run of samples this slot is in
+        if (run_first + 64u > n_samples) {
+            run_first = n_samples & ~63u;
+            for (run = 32u; run > 1u; run >>= 1) {
+                if ((n_samples - run_first) & run) {
+                    if (s_slot < run_first + run) break;
+                    run_first += run;
+                }
+            }
+        }
+        const uint32_t area_log2 = 6u - (31u - (uint32_t)__clz((int)run));           // pixels of a wave = 64 / run
+        const uint32_t bw_log2 = area_log2 >> 1, bh_log2 = area_log2 - bw_log2;        // 1x1, 1x2, 2x2, 2x4, 4x4, 4x8, 8x8 (wide x high)
+        const uint32_t rem = slot - run_first * B.npix;
+        const uint32_t npix8 = B.width * (B.rows & ~7u);  // the rows that make whole strips of 8; the others follow, along their rows
+        if (rem < run * npix8) {
+            const uint32_t blk = rem >> 6, inner = rem & 63u;
+            const uint32_t s_in = inner >> area_log2, in_px = inner & ((1u << area_log2) - 1u);
+            const uint32_t py = in_px >> bw_log2, px = in_px & ((1u << bw_log2) - 1u);
+            const uint32_t across = B.width >> bw_log2, by = blk / across, bx = blk - by * across;
+            pid = (run_first + s_in) * B.npix + ((by << bh_log2) + py) * B.width + (bx << bw_log2) + px;
+        } else {
+            const uint32_t rest = rem - run * npix8, tail_px = B.npix - npix8, s_in = rest / tail_px;
+            pid = (run_first + s_in) * B.npix + npix8 + (rest - s_in * tail_px);
+        }
+    } else if (B.blocked) {  // the slot counts through 8 x 8 blocks of pixels (DBatch::blocked)
         const uint32_t sl = slot / B.npix, pl = slot - sl * B.npix;
         const uint32_t W8 = B.width * 8u, strip = pl / W8;
         uint32_t p = pl;  // (a last strip of fewer than 8 rows: along its rows, as pl counts them)
