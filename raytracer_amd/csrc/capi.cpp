@@ -1086,8 +1086,8 @@ struct Engine : EngineBase {
                 b.bns = std::min(spb, s0 + ns - b.bs0);
                 b.n_paths = (uint32_t)(npix * b.bns);
                 b.n_tiles = tiles_for(b.n_paths);
-                b.B = rtd::DBatch{W, H, j0, (uint32_t)npix, b.bs0, 0u, seed, (uint32_t)(npix / W), pixel_blocks && W % 8 == 0 && S.n_sweep == 0 ? 1u : 0u};  // (tree walks only: a sweep has no lanes to keep in step)
-                if (b.B.blocked && pixel_blocks_env == nullptr) b.B.blocked = 2u;  // pixels x samples per wave
+                b.B = rtd::DBatch{W, H, j0, (uint32_t)npix, b.bs0, 0u, seed, (uint32_t)(npix / W), pixel_blocks && W % 8 == 0 && (S.n_sweep == 0 || (pixel_blocks_env && pixel_blocks_env[0] == '2')) ? 1u : 0u};  // (tree walks only: a sweep has no lanes to keep in step; =2 forces it, A/B runs)
+                if (b.B.blocked && (pixel_blocks_env == nullptr || pixel_blocks_env[0] == '2')) b.B.blocked = 2u;  // pixels x samples per wave
                 b.depth = 0;
                 b.known_depth = 0;
                 b.known_alive = b.n_paths;

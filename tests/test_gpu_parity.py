@@ -286,7 +286,10 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_TAIL": "0"}),
         ("blocks_ball", {"RT_TAIL": "0"}),
         ("blue_ball", {"RT_TAIL": "1000000000"}),              # the whole render after bounce 4 in the tail launch
-        ("cornell", {"RT_PIXEL_BLOCKS": "0"}),                 # paths numbered along the pixel rows, not through 8 x 8 blocks
+        ("cornell", {"RT_PIXEL_BLOCKS": "2"}),                 # a sweep scene with the tree scenes' queue order (pixels x samples per wave)
+        ("knight", {"RT_PIXEL_BLOCKS": "1"}),                  # 8 x 8 blocks of pixels, sample by sample
+        ("blocks_ball", {"RT_PIXEL_BLOCKS": "1"}),
+        ("cornell", {"RT_PIXEL_BLOCKS": "0"}),                 # paths enter the queue along the pixel rows
         ("knight", {"RT_PIXEL_BLOCKS": "0"}),
         ("blocks_ball", {"RT_PIXEL_BLOCKS": "0"}),             # 96 x 54: a ragged last strip of 6 rows
         ("blocks_ball", {"RT_COOP": "0"}),                     # world tree without meshes: the world walk is what the groups share
