@@ -1018,7 +1018,13 @@ struct Engine : EngineBase {
         // The tail launch hands its paths out from a cursor, so it stays efficient with many more paths than are
         // resident at a time; what it saves is the wait for the slowest ray of every bounce.
         uint32_t tail_threshold = fused ? tail_threshold_fused : tail_threshold_tree;
-        if (const char* e = std::getenv("RT_TAIL")) tail_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
+        // Meshes: with the queue order of DBatch::blocked the tail launch (walk and shading in one kernel, every path at
+        // its own pace) beats a launch per bounce from 4 M paths down - but not for the first two bounces, whose rays
+        // are many and alike (knight 35.8 -> 35.0 ms, 1 M triangles 48.6 -> 46.5; 13 spp, where the whole batch is
+        // 4.7 M paths: 7.8 ms either way, 9.3 if the tail took bounce 0 too).
+        uint32_t tail_threshold_late = tail_threshold;  // from the third bounce on
+        if (!fused && S.nodes4 && S.has_meshes) tail_threshold_late = 4194304u;
+        if (const char* e = std::getenv("RT_TAIL")) tail_threshold = tail_threshold_late = (uint32_t)std::strtoul(e, nullptr, 10);
         // RT_PIXEL_BLOCKS=0: paths enter the queue along the pixel rows; =1: through 8 x 8 blocks of pixels, sample by
         // sample; unset: a wave holds several samples of a few neighbouring pixels (DBatch::blocked; same image always)
         const char* pixel_blocks_env = std::getenv("RT_PIXEL_BLOCKS");
@@ -1113,7 +1119,7 @@ struct Engine : EngineBase {
             if (b.depth - b.known_depth > runahead) return STEP_BLOCKED;
             const uint32_t depth = b.depth;
             const int in = (int)(depth & 1u), out = in ^ 1;
-            if (b.known_alive <= tail_threshold) {
+            if (b.known_alive <= (depth >= 2 ? tail_threshold_late : tail_threshold)) {
                 // The paths that are left go through all their remaining bounces in ONE launch, each at its own
                 // pace, instead of one launch per bounce that waits for the slowest ray (k_bounce, DTail).  The
                 // count is RUNAHEAD bounces old at most, i.e. an upper bound of what the launch will find.
