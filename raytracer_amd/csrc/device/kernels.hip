@@ -2279,7 +2279,11 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
         // lane whose path has ended takes the next one of the share, so the waves stay full until the queue is
         // empty, and the launch ends as long after that as its longest path.
         uint32_t extra_queries = 0, deepest = depth0, taken = 0;
+#ifdef RT_NO_COOP  // (A/B builds: what the group code costs the full waves)
+        constexpr bool COOP_MODE = false;
+#else
         constexpr bool COOP_MODE = walks_node4(MODE);  // (meshes: the mesh walk is shared out; without: the world walk)
+#endif
         const uint32_t CHUNK = max(64u, min(1024u, (total / (gridDim.x * (BLOCK / 64) * 8u)) & ~63u));
         uint32_t chunk_lo = 0, chunk_hi = 0;  // (wave-uniform) what is left of the wave's share
         bool exhausted = false;               // (wave-uniform)
@@ -2342,7 +2346,7 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
             if constexpr (COOP_MODE) {
                 const uint64_t live = __ballot(alive);
                 const int n_live = __popcll(live);
-                if (n_live <= S.coop) {  // (wave-uniform)
+                if (__builtin_expect(n_live <= S.coop, 0)) {  // (wave-uniform; rare next to the full waves: kept out of their registers' way)
                     const int G = n_live <= 1 ? 64 : n_live <= 2 ? 32 : n_live <= 4 ? 16 : n_live <= 8 ? 8 : n_live <= 16 ? 4 : 2;
                     const int group = (int)lane / G;
                     uint64_t rest = live;
