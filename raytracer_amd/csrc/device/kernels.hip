@@ -1679,7 +1679,8 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
         const bool got = closest_hit<T, MODE>(S, r, min_dist, max_dist, st, path, depth, &t, &w);
         {
             const uint32_t steps = g_lane_steps[threadIdx.x];
-            if (depth == g_ray_steps_depth && d < (1u << 23)) g_ray_steps[d] = (unsigned short)min(steps, 65535u);
+            if (depth == g_ray_steps_depth && d < (1u << 23))  // steps (12 bits) | octant of the direction << 12
+                g_ray_steps[d] = (unsigned short)(min(steps, 4095u) | ((r.d.x < (T)0.0 ? 1u : 0u) | (r.d.y < (T)0.0 ? 2u : 0u) | (r.d.z < (T)0.0 ? 4u : 0u)) << 12);
             atomicAdd(&g_step_hist[min(steps, 2047u)], 1ull);
             uint32_t longest = steps;
             for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));

@@ -41,7 +41,8 @@ for depth in (0, 1, 2, 4, 8):
     n -= n % 4096
     if n == 0:
         continue
-    s = buf[:n].astype(np.int64)
+    octant = (buf[:n] >> 12).astype(np.int64)
+    s = (buf[:n] & 4095).astype(np.int64)
 
     def cost(order_fn, group):
         g = s.reshape(-1, group)
@@ -55,6 +56,14 @@ for depth in (0, 1, 2, 4, 8):
         full = cost(lambda g: np.sort(g, axis=1), group)
         line += f"; in {group}s: mesh / no mesh {split / base * 100:.0f} %, sorted by length {full / base * 100:.0f} %"
     print(line)
+    for group in (256, 4096):  # the rays of a block / tile regrouped by the octant of their direction (order kept inside an octant)
+        g = s.reshape(-1, group)
+        o = octant.reshape(-1, group)
+        by_octant = np.take_along_axis(g, np.argsort(o, axis=1, kind="stable"), axis=1).reshape(-1, 64).max(axis=1).sum()
+        print(f"  regrouped by direction octant inside {group}s: {by_octant / base * 100:.0f} % of the wave-steps")
+        key = o + 8 * (g > 4)  # ... and by "walks the mesh" as well (16 kinds)
+        both = np.take_along_axis(g, np.argsort(key, axis=1, kind="stable"), axis=1).reshape(-1, 64).max(axis=1).sum()
+        print(f"  by octant and mesh / no mesh inside {group}s: {both / base * 100:.0f} %")
     if depth == 0:
         # primary rays: a wave is 64 neighbours of a pixel row; what if it were a block of pixels?  (image cropped to 64s)
         k = n // (W * H)
