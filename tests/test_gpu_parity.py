@@ -324,6 +324,29 @@ def test_traversal_layouts_agree_bit_for_bit(rt, gpu_scenes, name, env, monkeypa
         assert np.array_equal(hits_a[field], hits_b[field]), field
 
 
+@pytest.mark.parametrize("name,width,rows,spp", [("knight", 104, (13, 50), 67), ("blocks_ball", 96, (0, 54), 5), ("knight", 64, (8, 24), 130),
+                                                 ("blocks_ball", 100, (3, 40), 9)])
+def test_the_order_of_the_queue_does_not_change_the_image(rt, gpu_scenes, name, width, rows, spp, monkeypatch):
+    # k_raygen puts the paths into the queue in one of three orders (DBatch::blocked): along the pixel rows, through
+    # 8 x 8 blocks of pixels, or n samples each of 64 / n neighbouring pixels per wave (runs of 64, 32, ... samples;
+    # rows that do not fill a strip of 8 at the end; a width that is not a multiple of 8 falls back to rows).  A path
+    # is named by its row-major id in all of them, so sums, bytes and ray counts must be the same to the bit.
+    sc, _ = gpu_scenes(name)
+    H = sc.image_height(width)
+    j0, j1 = rows[0], min(rows[1], H)
+    results = []
+    for order in ("0", "1", None):
+        if order is None:
+            monkeypatch.delenv("RT_PIXEL_BLOCKS", raising=False)
+        else:
+            monkeypatch.setenv("RT_PIXEL_BLOCKS", order)
+        results.append(gpu_scenes(name)[1].render_rows(width, H, j0, j1, spp, 12, seed=31))
+    for rgb8, sums, st in results[1:]:
+        assert st.rays == results[0][2].rays
+        assert np.array_equal(sums, results[0][1])
+        assert np.array_equal(rgb8, results[0][0])
+
+
 def test_checkers_that_emit_and_checkers_that_do_not(rt, orc):
     # Checkered::emitted picks a part with sin(k u) sin(k v) (no PI), scatter with sin(k PI u) sin(k PI v)
     # (src/materials.rs:166-183).  The kernel skips the emitted() selection for a checker none of whose
