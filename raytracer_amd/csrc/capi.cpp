@@ -991,10 +991,12 @@ struct Engine : EngineBase {
         }();
         // While launches are timed one lane runs: a launch's duration is then its own, not stretched by the other lane's
         // kernels on the same CUs (what the roofline of a kernel is priced with).
-        const int K = fixed || time_launches ? 1
-                            : (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(lanes.size(), max_paths / npix),
-                                                                             npix * ns / std::max<uint64_t>(1, lane_min_paths)));
-        const uint64_t lane_paths = fixed ? (uint64_t)RT_NOALLOC_MAX_PATHS : std::max<uint64_t>(1, max_paths / (uint64_t)K);
+        const int K_untimed = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(lanes.size(), max_paths / npix),
+                                                                            npix * ns / std::max<uint64_t>(1, lane_min_paths)));
+        const int K = fixed || time_launches ? 1 : K_untimed;
+        // (a call with launch timing runs one lane, but cuts its batches as the same call without timing would: the
+        // lane's buffers then need not grow - freeing and allocating 9 GB cost the timed step of bench.py 3 ms)
+        const uint64_t lane_paths = fixed ? (uint64_t)RT_NOALLOC_MAX_PATHS : std::max<uint64_t>(1, max_paths / (uint64_t)K_untimed);
         if (npix > lane_paths || npix > 0xffffffffull) {
             if (fixed)
                 throw RtError{RT_ERR_INVALID, "rt_render_accum_device_noalloc: the row band holds more than " +
