@@ -993,7 +993,10 @@ struct Engine : EngineBase {
         // kernels on the same CUs (what the roofline of a kernel is priced with).
         const int K_untimed = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(lanes.size(), max_paths / npix),
                                                                             npix * ns / std::max<uint64_t>(1, lane_min_paths)));
-        const int K = fixed || time_launches ? 1 : K_untimed;
+        // RT_ONE_LANE=1: one lane at a time with the batches of the usual call (what launch timing does: for profiles
+        // whose per-launch durations are to be a kernel's own)
+        const char* one_lane_env = std::getenv("RT_ONE_LANE");
+        const int K = fixed || time_launches || (one_lane_env && one_lane_env[0] == '1') ? 1 : K_untimed;
         // (a call with launch timing runs one lane, but cuts its batches as the same call without timing would: the
         // lane's buffers then need not grow - freeing and allocating 9 GB cost the timed step of bench.py 3 ms)
         const uint64_t lane_paths = fixed ? (uint64_t)RT_NOALLOC_MAX_PATHS : std::max<uint64_t>(1, max_paths / (uint64_t)K_untimed);

@@ -20,9 +20,9 @@ timeout -k 10 300 $B --steps 5 --warmup 1 --scene two_spheres > $O/bench_two_sph
 timeout -k 10 500 $B --steps 3 --warmup 1 --scene knight --triangles 1000000 > $O/bench_knight_1m.json
 echo "kernel stats"
 for s in cornell knight blocks_ball; do
-  # (RT_LANES=1: per-launch durations that are the kernel's own, as in the timed step of the bench line; the default two
-  # lanes stretch them, see *_2lanes_kernel_stats.csv)
-  RT_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1_$s -- $B --steps 5 --warmup 1 --scene $s --no-cpu-baseline > $O/stats_$s.log 2>&1
+  # (RT_ONE_LANE=1: one lane at a time, batches cut as usual - per-launch durations that are the kernel's own, as in the
+  # timed step of the bench line; the default two lanes stretch them, see *_2lanes_kernel_stats.csv)
+  RT_ONE_LANE=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1_$s -- $B --steps 5 --warmup 1 --scene $s --no-cpu-baseline > $O/stats_$s.log 2>&1
   cp $(find $O/stats1_$s -name "*kernel_stats.csv" | head -1) $O/${s}_f64_kernel_stats.csv
   rm -rf $O/stats1_$s
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$s -- $B --steps 5 --warmup 1 --scene $s --no-cpu-baseline > $O/stats_$s.log 2>&1
@@ -31,7 +31,7 @@ for s in cornell knight blocks_ball; do
   rm -rf $O/stats_$s
 done
 echo "pmc"
-export RT_LANES=1
+export RT_ONE_LANE=1
 for s in cornell knight blocks_ball; do
   for c in fetch:FETCH_SIZE write:WRITE_SIZE "sq:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
     name=${c%%:*}; counters=${c#*:}
