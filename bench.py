@@ -392,7 +392,7 @@ def main() -> None:
                        with_cpu=not args.no_cpu_baseline)
     # BASELINE.json's metric names cornell AND knight: the default one-GPU run carries the knight line too.
     if world == 1 and args.scene == "cornell" and not args.no_extra and args.triangles == 0 and args.spp == 100:
-        extra = run_workload(args, "knight", max(2, min(args.steps, 3)), 1, torch, rt, parallel, dist, rank, local_rank, world,
+        extra = run_workload(args, "knight", max(2, min(args.steps, 5)), 1, torch, rt, parallel, dist, rank, local_rank, world,
                              with_cpu=not args.no_cpu_baseline)
         keys = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "data", "config", "roofline", "stage_ms_last_step",
                 "scene_setup_ms", "cpu_baseline")
