@@ -217,6 +217,13 @@ typedef struct rt_hit {
     int32_t world_index;          /* `world` entry the hit came through */
     int32_t front_face, material;
     double t, p[3], n[3], u, v;   /* HitRecord, src/hitting.rs:33-41 */
+    /* Tie evidence ("Tie handling"): the nearest distance >= tmin at which the ray meets a primitive
+     * OTHER than (owner, sub), whatever tmax is; +inf when there is none (and on a miss).  second_t == t is an exact
+     * tie: the reference then returns the first element of a list (src/hitting.rs:94) and the later leaf of a BVH
+     * (src/hitting.rs:219), which is what (owner, sub) names.  Found by a second, exhaustive walk inside rt_trace. */
+    double second_t;
+    int32_t inst_id;              /* index into rt_scene_desc.objects of the instance the hit came through; -1 on a miss */
+    int32_t pad;
 } rt_hit;
 int rt_trace(rt_context* ctx, const rt_ray* rays, size_t n, uint64_t seed, rt_hit* out);
 
@@ -241,6 +248,8 @@ typedef struct rt_stats {
     uint64_t rays_tail;   /* closest-hit queries issued inside tail launches (part of `rays`) */
     uint32_t tail_launches;
     uint32_t extend_kernel; /* which kernel ms_extend times: 0 k_extend, 1 k_extend_refill, 2 k_bounce (fused) */
+    uint64_t paths_tail;  /* paths that entered tail launches (two-kernel bounces only, like rays_tail) */
+    uint64_t reserved;
 } rt_stats;
 /* ms_extend / ms_shade / ms_tail are filled only while launch timing is on: a HIP event either side of every launch
  * costs the stream about 5 us each (0.7 ms of a 21 ms image), so it is off by default; rays, paths, launch counts

@@ -33,7 +33,8 @@ PRECISION_F32 = 1
 RAY_DTYPE = np.dtype([("o", "<f8", 3), ("d", "<f8", 3), ("time", "<f8"), ("tmin", "<f8"), ("tmax", "<f8")])
 HIT_DTYPE = np.dtype(
     [("hit", "<i4"), ("owner", "<i4"), ("sub", "<i4"), ("world_index", "<i4"), ("front_face", "<i4"),
-     ("material", "<i4"), ("t", "<f8"), ("p", "<f8", 3), ("n", "<f8", 3), ("u", "<f8"), ("v", "<f8")]
+     ("material", "<i4"), ("t", "<f8"), ("p", "<f8", 3), ("n", "<f8", 3), ("u", "<f8"), ("v", "<f8"),
+     ("second_t", "<f8"), ("inst_id", "<i4"), ("pad", "<i4")]
 )
 
 
@@ -54,6 +55,7 @@ class RtStats(C.Structure):
         ("ms_shade", C.c_double), ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32),
         ("batches", C.c_uint32), ("max_depth_reached", C.c_uint32),
         ("ms_tail", C.c_double), ("rays_tail", C.c_uint64), ("tail_launches", C.c_uint32), ("extend_kernel", C.c_uint32),
+        ("paths_tail", C.c_uint64), ("reserved", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:

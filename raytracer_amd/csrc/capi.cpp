@@ -248,8 +248,8 @@ struct OwnedWork {
             w.sample_capacity = n_samples;
         }
         if (with_ids) {
-            hids.ensure(w.capacity * 3);
-            tminmax.ensure(w.capacity * 2);
+            hids.ensure(w.capacity * 4);     // owner, sub, world_index, inst
+            tminmax.ensure(w.capacity * 3);  // tmin, tmax, second_t
         }
         for (int k = 0; k < 2; k++) {
             w.qslab[k] = qslab[k].p;
@@ -842,11 +842,13 @@ struct Engine : EngineBase {
     static rtd::DHits<T> hits(const Work<T>& w, bool with_ids) {
         T* b = w.hslab;
         size_t n = w.capacity;
-        rtd::DHits<T> h{b, (uint64_t)n, w.hmat, nullptr, nullptr, nullptr};
+        rtd::DHits<T> h{b, (uint64_t)n, w.hmat, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (with_ids) {
             h.owner = w.hids;
             h.sub = w.hids + n;
             h.world_index = w.hids + 2 * n;
+            h.inst = w.hids + 3 * n;
+            h.second = w.tminmax + 2 * n;
         }
         return h;
     }
@@ -923,6 +925,7 @@ struct Engine : EngineBase {
             rtd::Launch<T>::load_rays(io_f64.p, (uint32_t)m, q, tmin, tmax, w.tile_counts[0], stream);
             rtd::launch_scan_tiles(w.tile_counts[0], tiles_for(m), w.tile_offsets, nullptr, w.counts, nullptr, nullptr, stream);
             launch_extend(w, stream, B, q, h, tmin, tmax, 0, tiles_for(m), grid_for(m));
+            rtd::Launch<T>::second(S, B, q, h, tmin, (uint32_t)m, stream);  // rt_hit::second_t: a second, exhaustive walk
             rtd::Launch<T>::store_hits(q, h, (uint32_t)m, io_hits.p, stream);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipMemcpyAsync(out + base, io_hits.p, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
@@ -1229,7 +1232,10 @@ struct Engine : EngineBase {
             LaneRun& R = runs[(size_t)k];
             if (R.next_batch == (uint32_t)k) continue;
             stats->rays += R.lane->readback[0] + R.lane->readback[1];
-            if (!fused) stats->rays_tail += R.lane->readback[1] + R.lane->readback[2];
+            if (!fused) {
+                stats->rays_tail += R.lane->readback[1] + R.lane->readback[2];
+                stats->paths_tail += R.lane->readback[2];
+            }
             deepest = std::max(deepest, std::min(std::max(R.deepest, (uint32_t)R.lane->readback[3]), max_bounces));
             stats->extend_launches += R.n_extend;
             stats->shade_launches += R.n_shade;
@@ -1537,6 +1543,7 @@ int rt_render_rows(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0
                 stats->ms_total += part.ms_total; stats->ms_extend += part.ms_extend; stats->ms_shade += part.ms_shade;
                 stats->extend_launches += part.extend_launches; stats->shade_launches += part.shade_launches;
                 stats->ms_tail += part.ms_tail; stats->rays_tail += part.rays_tail; stats->tail_launches += part.tail_launches;
+                stats->paths_tail += part.paths_tail;
                 stats->extend_kernel = part.extend_kernel;
                 stats->batches += part.batches;
                 stats->max_depth_reached = std::max(stats->max_depth_reached, part.max_depth_reached);

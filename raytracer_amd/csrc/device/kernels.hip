@@ -1708,6 +1708,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
                 h.owner[i] = sf.owner;
                 h.sub[i] = sf.sub;
                 h.world_index[i] = S.objects[w.obj].world_index;
+                h.inst[i] = w.obj;
             }
         } else {
             h.mat_front[i] = RT_MISS;
@@ -1899,6 +1900,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend_refill(DScene
                         h.owner[i] = sf.owner;
                         h.sub[i] = sf.sub;
                         h.world_index[i] = S.objects[best.obj].world_index;
+                        h.inst[i] = best.obj;
                     }
                 } else {
                     h.mat_front[i] = RT_MISS;
@@ -2405,6 +2407,150 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
     }
 }
 
+// ------------------------------------------------------------------ rt_hit::second_t (rt_trace only)
+// The nearest distance >= tmin at which the ray meets a primitive other than the winner (owner, sub), whatever tmax
+// is: what tells an exact tie (second_t == t), where the reference's answer rests on its list order (first wins,
+// src/hitting.rs:94) and leaf order (later wins, :219).  A second walk of its own, so that the render kernels carry
+// nothing for it: every primitive whose box the ray's line can reach is asked for its candidate distance - a rect,
+// triangle or plane where the line crosses it, a sphere at its first root >= tmin, a medium where its draw puts the
+// scatter event - and the smallest one from another primitive is kept (the walk is bounded by it, nothing else).
+// Stack: a private array (the binary trees are at most 64 deep each: world, mesh, a medium boundary's mesh).
+struct PrivStack {
+    static constexpr bool COOP = false;
+    int32_t* base;
+    __device__ __forceinline__ void put(int e, int32_t v) { base[e] = v; }
+    __device__ __forceinline__ int32_t get(int e) const { return base[e]; }
+    __device__ __forceinline__ bool room(int, int) const { return false; }
+    __device__ __forceinline__ void put_near(int e, int32_t v) { base[e] = v; }
+};
+template <typename T>
+struct Second {
+    T best, min_dist;
+    int owner, sub;
+    __device__ __forceinline__ void consider(T t, int o, int s) {  // (NaN fails t >= min_dist)
+        if (t >= min_dist && (o != owner || s != sub) && t < best) best = t;
+    }
+};
+// Depth-first over a DNode2 tree from `root`: leaf(payload, sp) for every leaf whose padded box the ray reaches
+// between min_dist and the best candidate so far.
+template <typename T, typename LEAF>
+__device__ __forceinline__ void walk2_all(const DScene<T>& S, const Ray<T>& r, int root, float shift, PrivStack st, int sp0, const Second<T>& sc, LEAF leaf) {
+    const RayF f = ray_f32(r, shift);
+    const float tmin32 = round_down(sc.min_dist - (T)shift);
+    int sp = sp0;
+    int32_t next = root;
+    for (;;) {
+        if (next == RT_EMPTY) {
+            if (sp == sp0) return;
+            next = st.get(--sp);
+        }
+        if (next < 0) {
+            leaf(-1 - next, sp);
+            next = RT_EMPTY;
+            continue;
+        }
+        const Node2Regs n = load_node2(S.nodes2, next);
+        const float bound32 = round_up(sc.best - (T)shift);
+        const int32_t c0 = n.child(0), c1 = n.child(1);
+        float e0, e1;
+        const bool h0 = c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32, &e0);
+        const bool h1 = c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32, &e1);
+        next = RT_EMPTY;
+        if (h0 && h1) {
+            next = c0;
+            st.put(sp++, c1);
+        } else if (h0) {
+            next = c0;
+        } else if (h1) {
+            next = c1;
+        }
+    }
+}
+template <typename T>
+__device__ void object_candidates(const DScene<T>& S, int oi, const Ray<T>& world_ray, PrivStack st, int sp, float shift, PathRef path,
+                                  Second<T>& sc) {
+    const DObject ob = S.objects[oi];
+    const T inf = Lim<T>::inf();
+    if (ob.kind == RT_OBJ_MEDIUM) {  // the scatter event itself; the boundary's own crossings are not candidates
+        T t;
+        int prim;
+        if (medium_hit<T, false, FEAT_ALL>(S, ob, world_ray, sc.min_dist, inf, st, sp, shift, path, 0u, &t, &prim)) sc.consider(t, S.media[prim].owner, 0);
+        return;
+    }
+    Ray<T> r = world_ray;
+    if (ob.xform >= 0) r = to_object_space(S.xforms[ob.xform], world_ray);
+    switch (ob.kind) {
+        case RT_OBJ_RECTS:
+            for (int k = 0; k < ob.count; k++) {
+                const DRect<T> q = S.rects[ob.first + k];
+                const int axis = q.axis, ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
+                const T t = (q.k - comp(r.o, axis)) / comp(r.d, axis);
+                const T a = comp(r.o, ia) + t * comp(r.d, ia), b = comp(r.o, ib) + t * comp(r.d, ib);
+                if (!(a < q.a0 || a > q.a1 || b < q.b0 || b > q.b1)) sc.consider(t, q.owner, q.sub);
+            }
+            break;
+        case RT_OBJ_SPHERE: {
+            const DSphere<T> s = S.spheres[ob.first];
+            T t;
+            if (distance_to_sphere(r, ld3(s.centre), s.radius, sc.min_dist, inf, &t)) sc.consider(t, s.owner, 0);
+            break;
+        }
+        case RT_OBJ_MOVING_SPHERE: {
+            const DMovingSphere<T> s = S.moving_spheres[ob.first];
+            T t;
+            if (distance_to_sphere(r, moving_centre(s, r.time), s.radius, sc.min_dist, inf, &t)) sc.consider(t, s.owner, 0);
+            break;
+        }
+        case RT_OBJ_TRIANGLE: {
+            const DTriangle<T> tr = S.triangles[ob.first];
+            V3<T> sol;
+            if (line_plane_collision(r.o, r.d, ld3(tr.point), ld3(tr.vec1), ld3(tr.vec2), &sol) &&
+                !(sol.y < (T)0.0 || sol.z < (T)0.0 || sol.y + sol.z > (T)1.0))
+                sc.consider(sol.x, tr.owner, tr.sub);
+            break;
+        }
+        case RT_OBJ_PLANE: {
+            const DPlane<T> pl = S.planes[ob.first];
+            V3<T> sol;
+            if (line_plane_collision(r.o, r.d, ld3(pl.point), ld3(pl.vec1), ld3(pl.vec2), &sol)) sc.consider(sol.x, pl.owner, 0);
+            break;
+        }
+        case RT_OBJ_BLAS:
+            walk2_all(S, r, ob.first, shift, st, sp, sc, [&](int tri, int) {
+                const DTriangle<T> tr = S.triangles[tri];
+                V3<T> sol;
+                if (line_plane_collision(r.o, r.d, ld3(tr.point), ld3(tr.vec1), ld3(tr.vec2), &sol) &&
+                    !(sol.y < (T)0.0 || sol.z < (T)0.0 || sol.y + sol.z > (T)1.0))
+                    sc.consider(sol.x, tr.owner, tr.sub);
+            });
+            break;
+        default: break;
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_second(DScene<T> S, DBatch B, DQueue<T> q, DHits<T> h, const T* tmin_arr, uint32_t n) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const T inf = Lim<T>::inf();
+    if (h.mat_front[i] == RT_MISS) {
+        h.second[i] = inf;
+        return;
+    }
+    int32_t stack[192];
+    PrivStack st{stack};
+    const Ray<T> r = load_ray(q, i);
+    Second<T> sc{inf, tmin_arr[i], h.owner[i], h.sub[i]};
+    const float shift = far_shift(S, r);
+    const PathRef path{&B, q.pid[i]};
+    for (int e = 0; e < S.n_top; e++) {
+        const int entry = S.top_list[e];
+        if (entry != RT_TOP_BVH) object_candidates(S, entry, r, st, 0, shift, path, sc);
+        else if (S.tlas_root >= 0)
+            walk2_all(S, r, S.tlas_root, shift, st, 0, sc, [&](int oi, int sp) { object_candidates(S, oi, r, st, sp, shift, path, sc); });
+    }
+    h.second[i] = sc.best;
+}
+
 // colour += cast_ray(..) over the samples of a batch, in sample order (src/main.rs:131-137).
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_accumulate(const T* sample_rgb, uint32_t npix, uint32_t n_samples, double* accum) {
@@ -2455,6 +2601,7 @@ __global__ void __launch_bounds__(BLOCK) k_store_hits(DQueue<T> q, DHits<T> h, u
     if (mf == RT_MISS) {
         o.hit = 0; o.owner = -1; o.sub = 0; o.world_index = -1; o.front_face = 0; o.material = -1;
         o.t = 0; o.p[0] = o.p[1] = o.p[2] = 0; o.n[0] = o.n[1] = o.n[2] = 0; o.u = o.v = 0;
+        o.second_t = (double)Lim<double>::inf(); o.inst_id = -1;
     } else {
         Ray<T> r = load_ray(q, i);
         T t = h.t()[i];
@@ -2467,7 +2614,10 @@ __global__ void __launch_bounds__(BLOCK) k_store_hits(DQueue<T> q, DHits<T> h, u
         o.p[0] = (double)p.x; o.p[1] = (double)p.y; o.p[2] = (double)p.z;
         o.n[0] = (double)h.nx()[i]; o.n[1] = (double)h.ny()[i]; o.n[2] = (double)h.nz()[i];
         o.u = (double)h.u()[i]; o.v = (double)h.v()[i];
+        o.second_t = (double)h.second[i];
+        o.inst_id = h.inst[i];
     }
+    o.pad = 0;
     out[i] = o;
 }
 
@@ -2592,6 +2742,10 @@ void Launch<T>::load_rays(const double* rays9, uint32_t n, DQueue<T> q, T* tmin,
     hipLaunchKernelGGL(k_load_rays<T>, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, rays9, n, q, tmin, tmax, tile_counts);
 }
 template <typename T>
+void Launch<T>::second(const DScene<T>& S, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_second<T>, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, S, B, q, h, tmin, n);
+}
+template <typename T>
 void Launch<T>::store_hits(DQueue<T> q, DHits<T> h, uint32_t n, void* out, hipStream_t st) {
     hipLaunchKernelGGL(k_store_hits<T>, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, st, q, h, n, (rt_hit*)out);
 }
@@ -2623,6 +2777,7 @@ void launch_quantize(const double* accum, uint64_t n_pixels, uint32_t spp_total,
                                    const uint32_t*, uint32_t*, uint32_t, int, hipStream_t);                                      \
     template void Launch<T>::accumulate(const T*, uint32_t, uint32_t, double*, hipStream_t);                                     \
     template void Launch<T>::load_rays(const double*, uint32_t, DQueue<T>, T*, T*, uint32_t*, hipStream_t);                      \
+    template void Launch<T>::second(const DScene<T>&, const DBatch&, DQueue<T>, DHits<T>, const T*, uint32_t, hipStream_t);       \
     template void Launch<T>::store_hits(DQueue<T>, DHits<T>, uint32_t, void*, hipStream_t);                                      \
     template void Launch<T>::store_rays(DQueue<T>, uint32_t, double*, hipStream_t);
 #if RT_PART_HAS(0)

@@ -234,6 +234,8 @@ struct DHits {
 #endif
     uint32_t* mat_front;                    // material | front_face << 31; RT_MISS for a miss
     int32_t *owner, *sub, *world_index;     // only written when non-null (rt_trace)
+    int32_t* inst;                          // rt_trace: the DObject index of the instance that was hit
+    T* second;                              // rt_trace: rt_hit::second_t (k_second)
 };
 static constexpr uint32_t RT_MISS = 0x7fffffffu;
 #define RT_STACK_OVERFLOW 40  // per-lane traversal-stack entries beyond the LDS part (private memory, rarely touched)
@@ -284,6 +286,8 @@ struct Launch {
     static void accumulate(const T* sample_rgb, uint32_t npix, uint32_t n_samples, double* accum, hipStream_t st);
     static void load_rays(const double* rays9, uint32_t n, DQueue<T> q, T* tmin, T* tmax, uint32_t* tile_counts,
                           hipStream_t st);
+    // rt_trace: rt_hit::second_t of rays 0 .. n-1 (slot i = ray i) into h.second, after extend has filled h
+    static void second(const DScene<T>& S, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, uint32_t n, hipStream_t st);
     static void store_hits(DQueue<T> q, DHits<T> h, uint32_t n, void* out_rt_hit, hipStream_t st);
     static void store_rays(DQueue<T> q, uint32_t n, double* rays9, hipStream_t st);
 };

@@ -61,13 +61,22 @@ struct Rccl {
             handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
             if (handle) break;
         }
-        if (const char* path = std::getenv("RT_RCCL_LIB"); !handle && path && path[0]) handle = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+        // (dlerror() hands its text out once and clears it: read once, right after the dlopen that failed)
+        std::string last_failure;
+        auto open = [&](const char* file) {
+            handle = dlopen(file, RTLD_NOW | RTLD_GLOBAL);
+            if (!handle) {
+                const char* e = dlerror();
+                last_failure = e ? e : std::string(file) + " not found";
+            }
+        };
+        if (const char* path = std::getenv("RT_RCCL_LIB"); !handle && path && path[0]) open(path);
         for (const char* n : names) {
             if (handle) break;
-            handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            open(n);
         }
         if (!handle) {
-            why = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+            why = "cannot load RCCL: " + (last_failure.empty() ? std::string("librccl.so.1 not found") : last_failure);
             return false;
         }
         CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll");
@@ -189,6 +198,7 @@ void add_stats(rt_stats* total, const rt_stats& part, bool same_device) {
     total->shade_launches += part.shade_launches;
     total->tail_launches += part.tail_launches;
     total->rays_tail += part.rays_tail;
+    total->paths_tail += part.paths_tail;
     total->batches += part.batches;
     total->extend_kernel = part.extend_kernel;
     total->max_depth_reached = std::max(total->max_depth_reached, part.max_depth_reached);

@@ -24,14 +24,29 @@ REL_TOL = 1e-5       # north_star: hit t / normal within 1e-5 relative
 TIE_REL = 1e-9       # tie rule
 
 
+def tie_mask(h, second_t=None):
+    second_t = h["second_t"] if second_t is None else second_t
+    return (h["hit"] == 1) & (np.abs(second_t - h["t"]) <= TIE_REL * np.maximum(np.abs(h["t"]), 1e-300))
+
+
 def check_hits(got, want, second_t=None):
+    """got: rt_trace's records; want: the oracle's (second_t: its nearest other candidate, None for the far-origin test).
+    The tie mask comes from the LIBRARY's own rt_hit.second_t and must be the oracle's."""
     assert np.array_equal(got["hit"], want["hit"]), "hit / miss differs"
     hit = want["hit"] == 1
     same = (got["owner"] == want["owner"]) & (got["sub"] == want["sub"])
+    tie = tie_mask(got)
+    assert np.all(np.isposinf(got["second_t"][~hit])) and np.all(got["inst_id"][~hit] == -1)
+    assert np.all(got["inst_id"][hit] >= 0)
+    assert np.all(got["second_t"][hit] >= got["t"][hit] * (1 - TIE_REL)), "a candidate nearer than the hit"
     if second_t is not None:
-        tie = hit & (np.abs(second_t - want["t"]) <= TIE_REL * np.maximum(np.abs(want["t"]), 1e-300))
-    else:
-        tie = np.zeros_like(hit)
+        assert np.array_equal(tie, tie_mask(want, second_t)), "the library's tie flags are not the oracle's"
+        # the same second candidate where the two agree on the first (an exact tie names the same distance either way)
+        both = hit & same
+        finite = both & np.isfinite(second_t)
+        assert np.array_equal(np.isfinite(got["second_t"][both]), np.isfinite(second_t[both]))
+        err = np.abs(got["second_t"][finite] - second_t[finite]) / np.maximum(np.abs(second_t[finite]), 1e-300)
+        assert err.max(initial=0) <= REL_TOL, "second_t"
     assert np.all(same[hit & ~tie]), f"{(~same[hit & ~tie]).sum()} primitive ids differ on non-tied rays"
     # on a tie the GPU must still return one of the tied primitives: same distance
     tied = hit & tie & ~same
@@ -148,6 +163,29 @@ def test_exact_ties_follow_the_reference_rules(rt, orc):
     for f in ["hit", "owner", "sub", "material", "front_face"]:
         assert np.array_equal(got[f], want[f]), f
     assert np.array_equal(got["t"], want["t"])
+    # the library says so itself (rt_hit.second_t): exact ties on the first two rays, not on the third
+    assert np.array_equal(got["second_t"], want["second_t"])
+    assert np.all(got["second_t"][:2] == got["t"][:2]) and got["second_t"][2] > got["t"][2]
+    assert check_hits(got, want, want["second_t"]) == 2
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_inst_id_names_the_instance_that_was_hit(gpu_scenes, name):
+    # rt_hit.inst_id indexes rt_scene_desc.objects: that instance lists the primitive (owner, sub) and came through world_index
+    from test_scene_loader import _desc
+
+    g = np.load(os.path.join(GOLDEN, name + "_rays.npz"))
+    sc, r = gpu_scenes(name)
+    d = _desc(sc)
+    got = r.trace(g["rays"], seed=int(g["seed"]))
+    objs = d["objects"]
+    for h in got[got["hit"] == 1][::7]:
+        o = objs[int(h["inst_id"])]
+        assert o.world_index == h["world_index"]
+        if o.kind == 2:   # RT_OBJ_RECTS: one of the instance's rects
+            assert any(d["rects"][o.first + k].owner == h["owner"] and d["rects"][o.first + k].sub == h["sub"] for k in range(o.count))
+        elif o.kind == 0:
+            assert d["spheres"][o.first].owner == h["owner"]
 
 
 @pytest.mark.parametrize("name", SCENES)
