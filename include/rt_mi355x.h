@@ -200,7 +200,8 @@ typedef struct rt_upload_stats {
     double ms_copy;        /* host: record conversion + host-to-device copies of everything else */
     double ms_total;
     uint64_t bytes_device; /* scene bytes resident on the GPU */
-    uint32_t n_nodes2, n_nodes4, sah_trees, pad;
+    uint32_t n_nodes2, n_nodes4, sah_trees;
+    uint32_t needs_uv;     /* some material reads (u, v) (image textures, checkers): hit records carry them (16 B more each way) */
 } rt_upload_stats;
 int rt_get_upload_stats(rt_context* ctx, rt_upload_stats* out);
 

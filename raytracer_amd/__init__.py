@@ -66,11 +66,11 @@ class RtUploadStats(C.Structure):
     _fields_ = [
         ("ms_validate", C.c_double), ("ms_build", C.c_double), ("ms_copy", C.c_double), ("ms_total", C.c_double),
         ("bytes_device", C.c_uint64), ("n_nodes2", C.c_uint32), ("n_nodes4", C.c_uint32), ("sah_trees", C.c_uint32),
-        ("pad", C.c_uint32),
+        ("needs_uv", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:
-        return {name: getattr(self, name) for name, _ in self._fields_ if name != "pad"}
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 # Every symbol include/rt_mi355x.h declares: (name, restype, argtypes).

@@ -739,6 +739,7 @@ struct Engine : EngineBase {
         up_stats.n_nodes2 = (uint32_t)n_nodes2;
         up_stats.n_nodes4 = (uint32_t)(S.nodes4 ? nodes4.n : 0);
         up_stats.sah_trees = sah_trees ? 1u : 0u;
+        up_stats.needs_uv = S.needs_uv ? 1u : 0u;
         up_stats.bytes_device = nodes2.n * sizeof(rtd::DNode2) + (S.nodes4 ? nodes4.n * sizeof(rtd::DNode4) : 0) + objects.n * sizeof(rtd::DObject) +
                                 blocks.n * sizeof(rtd::DBlock<T>) + xforms.n * sizeof(rtd::DXform<T>) + spheres.n * sizeof(rtd::DSphere<T>) +
                                 moving_spheres.n * sizeof(rtd::DMovingSphere<T>) + rects.n * sizeof(rtd::DRect<T>) +

@@ -1,45 +1,54 @@
 #!/bin/bash
-# Collects the round's evidence on the GPU box: bench lines, rocprofv3 kernel stats, PMC traffic and instruction counts.
-# usage: scripts/profile_round.sh <tag>     (writes under gpurun_out/<tag>/; copy what is to be judged into profiles/<tag>/)
-# PMC passes: one rocprofv3 --pmc run each (FETCH_SIZE, WRITE_SIZE, the SQ set), never together with a trace.
+# Collects a round's evidence on the GPU box.  usage: scripts/profile_round.sh <tag> <part>...   parts, in this order:
+#   mix    instruction-class calibration (bin/valu_mix: timing table + three --pmc passes)   -> valu_mix.txt, valu_mix_counters.txt, valu_mix.json
+#   pmc    rocprofv3 --pmc passes of one step per scene (scripts/pmc_passes.sh)               -> pmc.json, pmc_summary.txt
+#   bench  the bench lines (they price their kernels with the pmc.json / valu_mix.json made above) -> bench_*.json
+#   stats  rocprofv3 --kernel-trace --stats of the bench command, one lane and two lanes      -> *_kernel_stats.csv, timeline_*.txt
+# Everything lands under gpurun_out/<tag>/ (and pmc.json / valu_mix.json also under profiles/<tag>/ of the box's copy of the tree,
+# where bench.py looks); copy what is to be judged into profiles/<tag>/ afterwards.  PMC passes are runs of their own, never
+# together with a trace.
 set -e
-tag=${1:-r02}
+tag=$1; shift
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
-mkdir -p $O
+mkdir -p $O $R/profiles/$tag
 cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --no-extra"
-echo "bench lines"
-timeout -k 10 300 python3 $R/bench.py --steps 5 --warmup 1 > $O/bench_default.json
-for s in cornell knight blocks_ball; do
-  timeout -k 10 300 $B --steps 5 --warmup 1 --scene $s > $O/bench_$s.json
-  timeout -k 10 300 $B --steps 10 --warmup 2 --scene $s --spp 13 --no-cpu-baseline > $O/bench_${s}_13spp.json
-done
-timeout -k 10 300 $B --steps 5 --warmup 1 --scene globe > $O/bench_globe.json
-timeout -k 10 300 $B --steps 5 --warmup 1 --scene two_spheres > $O/bench_two_spheres.json
-timeout -k 10 500 $B --steps 3 --warmup 1 --scene knight --triangles 1000000 > $O/bench_knight_1m.json
-echo "kernel stats"
-for s in cornell knight blocks_ball; do
-  # (RT_ONE_LANE=1: one lane at a time, batches cut as usual - per-launch durations that are the kernel's own, as in the
-  # timed step of the bench line; the default two lanes stretch them, see *_2lanes_kernel_stats.csv)
-  RT_ONE_LANE=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1_$s -- $B --steps 5 --warmup 1 --scene $s --no-cpu-baseline > $O/stats_$s.log 2>&1
-  cp $(find $O/stats1_$s -name "*kernel_stats.csv" | head -1) $O/${s}_f64_kernel_stats.csv
-  rm -rf $O/stats1_$s
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$s -- $B --steps 5 --warmup 1 --scene $s --no-cpu-baseline > $O/stats_$s.log 2>&1
-  cp $(find $O/stats_$s -name "*kernel_stats.csv" | head -1) $O/${s}_f64_2lanes_kernel_stats.csv
-  python3 $R/scripts/timeline.py $O/stats_$s 200 > $O/timeline_${s}.txt || true
-  rm -rf $O/stats_$s
-done
-echo "pmc"
-export RT_ONE_LANE=1
-for s in cornell knight blocks_ball; do
-  for c in fetch:FETCH_SIZE write:WRITE_SIZE "sq:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
-    name=${c%%:*}; counters=${c#*:}
-    timeout -s KILL 150 rocprofv3 --pmc $counters --output-format csv -d $O/pmc_${name}_$s -- $B --steps 1 --warmup 0 --scene $s --no-cpu-baseline > $O/pmc_${name}_$s.log 2>&1
+for part in "$@"; do
+case $part in
+mix)
+  bash $R/scripts/valu_mix_pmc.sh $tag > /dev/null
+  python3 $R/scripts/make_valu_mix.py $O/valu_mix.txt > $O/valu_mix.json
+  cp $O/valu_mix.json $R/profiles/$tag/valu_mix.json
+  ;;
+pmc)
+  bash $R/scripts/pmc_passes.sh $tag cornell knight blocks_ball globe two_spheres
+  ;;
+bench)
+  timeout -k 10 300 python3 $R/bench.py --steps 5 --warmup 1 > $O/bench_default.json
+  for s in cornell knight blocks_ball globe two_spheres; do
+    timeout -k 10 300 $B --steps 5 --warmup 1 --scene $s > $O/bench_$s.json
   done
+  for s in cornell knight blocks_ball; do
+    for spp in 50 25 13 1; do
+      timeout -k 10 300 $B --steps 10 --warmup 2 --scene $s --spp $spp --no-cpu-baseline > $O/bench_${s}_${spp}spp.json
+    done
+  done
+  timeout -k 10 500 $B --steps 3 --warmup 1 --scene knight --triangles 1000000 > $O/bench_knight_1m.json
+  ;;
+stats)
+  for s in cornell knight blocks_ball globe two_spheres; do
+    # (RT_ONE_LANE=1: one lane at a time, batches cut as usual - per-launch durations that are the kernel's own, as in the
+    # instrumented step of the bench line; the default two lanes stretch them, see *_2lanes_kernel_stats.csv)
+    RT_ONE_LANE=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1_$s -- $B --steps 5 --warmup 1 --scene $s --no-cpu-baseline --no-launch-timing > $O/stats_$s.log 2>&1
+    cp $(find $O/stats1_$s -name "*kernel_stats.csv" | head -1) $O/${s}_f64_kernel_stats.csv
+    rm -rf $O/stats1_$s
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$s -- $B --steps 5 --warmup 1 --scene $s --no-cpu-baseline --no-launch-timing > $O/stats_$s.log 2>&1
+    cp $(find $O/stats_$s -name "*kernel_stats.csv" | head -1) $O/${s}_f64_2lanes_kernel_stats.csv
+    python3 $R/scripts/timeline.py $O/stats_$s 200 > $O/timeline_${s}.txt || true
+    rm -rf $O/stats_$s $O/stats_$s.log
+  done
+  ;;
+esac
+echo "part $part done"
 done
-for d in $(ls -d $O/pmc_*/ | xargs -n1 basename); do echo "== $d"; python3 $R/scripts/pmc_summary.py $O/$d | grep -E "k_bounce|k_extend|k_shade|k_raygen|k_accumulate" || true; done > $O/pmc_summary.txt
-python3 $R/scripts/make_traffic.py $O > $O/traffic.json
-python3 $R/scripts/make_valu.py $O > $O/valu.json
-rm -rf $O/pmc_*/
-cat $O/valu.json | head -40
