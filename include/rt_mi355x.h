@@ -85,7 +85,7 @@ typedef struct rt_plane {         /* src/objects.rs:567-629 */
 
 typedef struct rt_medium {        /* ConstantMedium, src/objects.rs:384-460 */
     double neg_inv_density;
-    int32_t boundary_object;      /* rt_object index; must not itself be a medium */
+    int32_t boundary_object;      /* rt_object index; may be a medium whose own boundary is not one (two levels, src/objects.rs:404-409) */
     int32_t material;             /* phase function */
     int32_t owner;
     uint32_t rng_key;             /* volume-stream key of this medium instance (RNG) */

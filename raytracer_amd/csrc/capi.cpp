@@ -171,7 +171,13 @@ void validate(const rt_scene_desc& d) {
         const rt_medium& m = d.media[i];
         if (!mat_ok(m.material)) bad("medium material");
         if (m.boundary_object < 0 || (uint64_t)m.boundary_object >= d.n_objects) bad("medium boundary index");
-        if (d.objects[m.boundary_object].kind == RT_OBJ_MEDIUM) bad("medium boundary is a medium");
+        if (d.objects[m.boundary_object].kind == RT_OBJ_MEDIUM) {  // a medium bounded by a medium: one level (kernels.hip, boundary_hit)
+            const rt_object& inner = d.objects[m.boundary_object];
+            if (inner.first < 0 || (uint64_t)inner.first >= d.n_media) bad("medium boundary index");
+            const rt_medium& im = d.media[inner.first];
+            if (im.boundary_object < 0 || (uint64_t)im.boundary_object >= d.n_objects) bad("medium boundary index");
+            if (d.objects[im.boundary_object].kind == RT_OBJ_MEDIUM) bad("media nested more than two deep");
+        }
     }
     for (uint64_t i = 0; i < d.n_objects; i++) {
         const rt_object& o = d.objects[i];
@@ -378,6 +384,7 @@ struct Engine : EngineBase {
     int stack_depth = 16;
     int stack_need4 = 0;  // stack entries a four-wide mesh walk can need (0: no four-wide trees)
     bool sah_trees = false;  // the four-wide trees were regrouped by SAH (else: the reference's grouping, folded)
+    bool nested_media = false;  // some medium's boundary is a medium: the general four-wide kernel runs the scene
     rtd::DScene<T> S;
     DevBuf<rtd::DNode2> nodes2;
     size_t n_nodes2 = 0;
@@ -724,11 +731,26 @@ struct Engine : EngineBase {
             if (d.objects[i].kind == RT_OBJ_MEDIUM) S.has_media = 1;
         }
         if (const char* e = std::getenv("RT_FEATURES"); e && e[0] == 'a') S.has_meshes = S.has_media = 1;  // "all": the general kernel (A/B runs, tests)
+        // A medium bounded by a medium (src/objects.rs:404-409 takes any Hittable): only the general four-wide kernel
+        // compiles the nested boundary query in (FEAT_NESTED_MEDIA), so such a scene takes it whatever else it holds.
+        nested_media = false;
+        for (uint64_t i = 0; i < d.n_media; i++)
+            if (d.objects[d.media[i].boundary_object].kind == RT_OBJ_MEDIUM) nested_media = true;
+        if (nested_media) {
+            if (!S.nodes4) throw RtError{RT_ERR_UNSUPPORTED, "a medium bounded by a medium needs the four-wide trees (world tree too deep, or RT_BVH4=0)"};
+            S.has_meshes = S.has_media = 1;
+        }
         S.needs_uv = 0;
         for (uint64_t i = 0; i < d.n_materials; i++)
             if (d.materials[i].image >= 0 || d.materials[i].type == RT_MAT_CHECKERED) S.needs_uv = 1;
         build_small_scene(d);
         build_sweep(d);
+        if (nested_media) {  // neither the sweep nor the LDS-staged walk carries the nested query
+            S.sweep = nullptr;
+            S.n_sweep = 0;
+            S.lean = 0;
+            std::memset(&small, 0, sizeof(small));
+        }
         if (std::getenv("RT_DEBUG"))
             std::fprintf(stderr, "rt_upload_scene: objects %llu, stack_depth %d, four-wide %s (stack need %d, lds cap %d), sweep %d%s\n",
                          (unsigned long long)d.n_objects, stack_depth, S.nodes4 ? (sah_trees ? "sah" : "folded") : "no", stack_need4,

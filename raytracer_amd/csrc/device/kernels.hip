@@ -942,7 +942,8 @@ struct Winner {
 // FEAT: which object kinds a kernel variant compiles in besides rect lists (scenes made of walls,
 // boxes and spheres get a much smaller kernel that needs no scratch memory).
 enum { FEAT_SPHERES = 1, FEAT_FLAT = 2 /* Triangle / Plane objects */, FEAT_BLAS = 4, FEAT_MEDIA = 8, FEAT_ALL = 15,
-       FEAT_BLAS4 = 16 /* meshes are walked through the four-wide tree */ };
+       FEAT_BLAS4 = 16 /* meshes are walked through the four-wide tree */,
+       FEAT_NESTED_MEDIA = 32 /* a medium's boundary may itself be a medium (one level) */ };
 
 template <typename T, bool UNIFORM, int FEAT, typename ST>
 __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, T min_dist, T max_dist,
@@ -1023,6 +1024,21 @@ __device__ bool object_hit(const DScene<T>& S, int oi, const Ray<T>& world_ray, 
         return simple_object_hit<T, UNIFORM, FEAT>(S, oi, world_ray, min_dist, max_dist, st, sp, shift, t_out, prim_out);
     return medium_hit<T, UNIFORM, FEAT>(S, ob, world_ray, min_dist, max_dist, st, sp, shift, path, depth, t_out, prim_out);
 }
+// boundary.hit(ray, lo, hi) of a ConstantMedium (src/objects.rs:404-409).  The boundary is any Hittable: where the
+// kernel is compiled for it (FEAT_NESTED_MEDIA: the general four-wide kernel and rt_trace's second walk) it may be another
+// medium, whose own hit - two queries of ITS boundary, its own draw - answers the query; that inner medium's
+// boundary is not a medium (checked when the scene is loaded / uploaded).
+template <typename T, bool UNIFORM, int FEAT, typename ST>
+__device__ __forceinline__ bool boundary_hit(const DScene<T>& S, int bo, const Ray<T>& r, T lo, T hi, ST st, int sp, float shift, PathRef path,
+                                             uint32_t depth, T* t_out) {
+    int ignore;
+    if constexpr ((FEAT & FEAT_NESTED_MEDIA) != 0) {
+        const DObject bob = rec<UNIFORM>(&S.objects[bo]);
+        if (bob.kind == RT_OBJ_MEDIUM)
+            return medium_hit<T, UNIFORM, (FEAT & ~FEAT_NESTED_MEDIA)>(S, bob, r, lo, hi, st, sp, shift, path, depth, t_out, &ignore);
+    }
+    return simple_object_hit<T, UNIFORM, FEAT>(S, bo, r, lo, hi, st, sp, shift, t_out, &ignore);
+}
 // ConstantMedium::hit, src/objects.rs:398-441.
 template <typename T, bool UNIFORM, int FEAT, typename ST>
 __device__ RT_MEDIUM_ATTR bool medium_hit(const DScene<T>& S, const DObject ob, const Ray<T>& world_ray, T min_dist, T max_dist, ST st,
@@ -1032,10 +1048,9 @@ __device__ RT_MEDIUM_ATTR bool medium_hit(const DScene<T>& S, const DObject ob, 
     if (ob.xform >= 0) r = to_object_space(rec<UNIFORM>(&S.xforms[ob.xform]), world_ray);
     const T inf = Lim<T>::inf();
     T t1, t2;
-    int ignore;
     // (the second query runs only in the lanes whose first one hit, so it is not wave-uniform)
-    if (!simple_object_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, -inf, inf, st, sp, shift, &t1, &ignore)) return false;
-    if (!simple_object_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, t1 + (T)0.0001, inf, st, sp, shift, &t2, &ignore)) return false;
+    if (!boundary_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, -inf, inf, st, sp, shift, path, depth, &t1)) return false;
+    if (!boundary_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, t1 + (T)0.0001, inf, st, sp, shift, path, depth, &t2)) return false;
     if (t1 < min_dist) t1 = min_dist;
     if (t2 > max_dist) t2 = max_dist;
     if (t1 >= t2) return false;
@@ -1058,7 +1073,7 @@ enum { WALK_NODE2 = 0, WALK_OWN_BOX_LDS = 1, WALK_SWEEP = 2, WALK_SWEEP_LEAN = 3
 constexpr bool walks_node4(int mode) { return mode >= WALK_NODE2_MESH4; }
 template <int MODE> struct WalkFeat {
     static constexpr int value = MODE == WALK_SWEEP_LEAN     ? FEAT_SPHERES
-                                 : MODE == WALK_NODE2_MESH4  ? (FEAT_ALL | FEAT_BLAS4)
+                                 : MODE == WALK_NODE2_MESH4  ? (FEAT_ALL | FEAT_BLAS4 | FEAT_NESTED_MEDIA)
                                  : MODE == WALK_NODE4_MESH   ? ((FEAT_ALL & ~FEAT_MEDIA) | FEAT_BLAS4)
                                  : MODE == WALK_NODE4_MEDIA  ? (FEAT_ALL & ~FEAT_BLAS)
                                  : MODE == WALK_NODE4_PLAIN  ? (FEAT_ALL & ~FEAT_BLAS & ~FEAT_MEDIA)
@@ -2474,7 +2489,8 @@ __device__ void object_candidates(const DScene<T>& S, int oi, const Ray<T>& worl
     if (ob.kind == RT_OBJ_MEDIUM) {  // the scatter event itself; the boundary's own crossings are not candidates
         T t;
         int prim;
-        if (medium_hit<T, false, FEAT_ALL>(S, ob, world_ray, sc.min_dist, inf, st, sp, shift, path, 0u, &t, &prim)) sc.consider(t, S.media[prim].owner, 0);
+        if (medium_hit<T, false, (FEAT_ALL | FEAT_NESTED_MEDIA)>(S, ob, world_ray, sc.min_dist, inf, st, sp, shift, path, 0u, &t, &prim))
+            sc.consider(t, S.media[prim].owner, 0);
         return;
     }
     Ray<T> r = world_ray;

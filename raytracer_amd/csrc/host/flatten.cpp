@@ -606,11 +606,16 @@ private:
             }
             case ObjectDef::ConstantMedium: {  // src/objects.rs:384-460
                 int bdepth = 0;
-                int32_t boundary = instantiate(o.prototype, Xf(), hash_combine(ctx, (uint32_t)oi), -1, &bdepth);
-                if (out_.objects[(size_t)boundary].kind == RT_OBJ_MEDIUM)
+                // (ConstantMedium::hit hands the ray it was given to boundary.hit: the boundary sees the same
+                // transform context, src/objects.rs:404-409)
+                int32_t boundary = instantiate(o.prototype, Xf(), ctx, -1, &bdepth);
+                // The boundary is any Hittable, another medium included (src/objects.rs:388-391).  The kernels answer a
+                // boundary query that is itself a medium test one level deep; deeper nestings are refused here.
+                if (out_.objects[(size_t)boundary].kind == RT_OBJ_MEDIUM &&
+                    out_.objects[(size_t)out_.media[(size_t)out_.objects[(size_t)boundary].first].boundary_object].kind == RT_OBJ_MEDIUM)
                     throw SceneError("Object " + o.name +
-                                     ": a constantMedium whose boundary is itself a constantMedium is not "
-                                     "supported by the GPU path");
+                                     ": constantMedium boundaries nested more than two deep (a medium bounded by a medium "
+                                     "bounded by a medium) are not supported by the GPU path");
                 rt_medium m;
                 m.neg_inv_density = -1.0 / o.density;
                 m.boundary_object = boundary;

@@ -419,7 +419,7 @@ def test_checkers_that_emit_and_checkers_that_do_not(rt, orc):
     assert sums.max() > 1.0  # the lamps are seen
 
 
-def _corners_scene(tmp, with_mesh, extra_spheres):
+def _corners_scene(tmp, with_mesh, extra_spheres, nested=False):
     """Every object kind and wrapper of the schema in one world: moving sphere, lone
     triangle, plane, rotateX / rotateY / rotateZ around translate, spotlight, media bounded by a sphere, a block
     and (with_mesh) a mesh, nested checker, image-free materials of every type."""
@@ -440,6 +440,18 @@ def _corners_scene(tmp, with_mesh, extra_spheres):
         ground: {type: "plane", point0: [0,0,0], point1: [1,0,0], point2: [0,0,1], uvRepeat: 2.0, material: "check"},
     """
     world = ["ball", "mover", "tri", "crateAt", "fog", "haze", "lamp", "ground"]
+    if nested:
+        # a medium whose boundary is a medium (src/objects.rs:404-409: any Hittable), the inner one also in the world, a
+        # second pair behind a transform
+        objs += """
+        fogOfFog: {type: "constantMedium", boundary: "fog", phaseFunction: "smoke", density: 2.0},
+        puffBall: {type: "sphere", centre: [0,0,0], radius: 0.8, material: "glass"},
+        puff: {type: "constantMedium", boundary: "puffBall", phaseFunction: "mist", density: 0.9},
+        puffAt: {type: "translate", prototype: "puff", offset: [2.6,2.6,0.4]},
+        puffOfPuff: {type: "constantMedium", boundary: "puffAt", phaseFunction: "smoke", density: 3.0},
+        puffTurned: {type: "rotateY", prototype: "puffOfPuff", degrees: 30},
+        """
+        world += ["fogOfFog", "puffTurned"]
     if with_mesh:
         obj = os.path.join(tmp, "tetra.obj")
         with open(obj, "w") as f:
@@ -463,7 +475,7 @@ def _corners_scene(tmp, with_mesh, extra_spheres):
                  k: {type: "solidColour", colour: [0.1,0.1,0.1]}, m: {type: "solidColour", colour: [0.7,0.7,0.8]}},
       materials: {red: {type: "lambertian", texture: "r"}, white: {type: "lambertian", texture: "w"},
                   black: {type: "lambertian", texture: "k"}, mirror: {type: "metal", albedo: [0.9,0.8,0.7], fuzz: 0.1},
-                  glass: {type: "dielectric", indexOfRefraction: 1.5}, mist: {type: "isotropic", albedo: "m"},
+                  glass: {type: "dielectric", indexOfRefraction: 1.5}, mist: {type: "isotropic", albedo: "m"}, smoke: {type: "isotropic", albedo: "k"},
                   tiles: {type: "checkered", odd: "white", even: "black", tileDensity: 4},
                   check: {type: "checkered", odd: "tiles", even: "red", tileDensity: 2}},
       objects: {%s},
@@ -471,12 +483,14 @@ def _corners_scene(tmp, with_mesh, extra_spheres):
     }""" % (objs, ", ".join('"%s"' % w for w in world))
 
 
-@pytest.mark.parametrize("with_mesh,extra_spheres", [(False, 0), (False, 14), (False, 150), (True, 0), (True, 150)])
-def test_every_object_kind_against_the_oracle(rt, orc, tmp_path, with_mesh, extra_spheres):
+@pytest.mark.parametrize("with_mesh,extra_spheres,nested", [(False, 0, False), (False, 14, False), (False, 150, False), (True, 0, False),
+                                                           (True, 150, False), (False, 0, True), (True, 150, True)])
+def test_every_object_kind_against_the_oracle(rt, orc, tmp_path, with_mesh, extra_spheres, nested):
     # (False, 0): a world of 7 leaves is swept; (False, 14): own-box tree staged in LDS; (False, 150): too large
     # for LDS - four-wide world tree, k_extend_refill with media; (True, ..): meshes and media together - the
-    # general four-wide kernel, a medium bounded by a mesh
-    text = _corners_scene(str(tmp_path), with_mesh, extra_spheres)
+    # general four-wide kernel, a medium bounded by a mesh; nested: media bounded by media (plain and behind
+    # transforms), which only the general four-wide kernel answers - a small world takes it too then
+    text = _corners_scene(str(tmp_path), with_mesh, extra_spheres, nested)
     scene = rt.Scene.from_text(text)
     o = orc.OracleScene.from_text(text)
     r = rt.Renderer(0)

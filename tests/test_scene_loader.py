@@ -128,13 +128,19 @@ def test_forward_references_and_instancing(rt):
     assert c["xforms"] == 3 and c["media"] == 1
 
 
-def test_medium_of_medium_is_rejected(rt):
+def test_medium_bounded_by_a_medium_loads_and_deeper_nestings_are_refused(rt):
+    # ConstantMedium::new takes any Hittable as its boundary (src/objects.rs:388-391), another medium included: two
+    # levels flatten (the kernels answer the nested boundary query); three are refused with a message
     objs = ('b: {type: "block", corner0: [0,0,0], corner1: [1,1,1], material: "m"},'
             'f1: {type: "constantMedium", boundary: "b", phaseFunction: "m", density: 0.1},'
             'f2: {type: "constantMedium", boundary: "f1", phaseFunction: "m", density: 0.1}')
+    sc = rt.Scene.from_text(scene_text(objs=objs, world='"f2"'))
+    c = sc.counts()
+    assert c["media"] == 2 and c["objects"] == 3 and c["rects"] == 6     # f2, its boundary f1, f1's boundary b
+    objs += ', f3: {type: "constantMedium", boundary: "f2", phaseFunction: "m", density: 0.1}'
     with pytest.raises(rt.RtError) as e:
-        rt.Scene.from_text(scene_text(objs=objs, world='"f2"'))
-    assert "not supported" in e.value.message
+        rt.Scene.from_text(scene_text(objs=objs, world='"f3"'))
+    assert "not supported" in e.value.message and "two deep" in e.value.message
 
 
 def test_obj_loader(rt, tmp_path):
