@@ -116,6 +116,8 @@ MeshData parse_obj_mesh(const std::string& text, const std::string& object_name,
 // Baseline JPEG / PPM(P6) / PNG-less image reader standing in for image 0.23.12
 // (src/textures.rs:32-36): decodes to RGB8.
 ImageRGB8 load_image_rgb8(const std::string& path);
-ImageRGB8 decode_jpeg_baseline(const uint8_t* data, size_t size);
+ImageRGB8 decode_jpeg(const uint8_t* data, size_t size);           // baseline, extended and progressive Huffman JPEG
+ImageRGB8 decode_jpeg_baseline(const uint8_t* data, size_t size);  // (the name earlier rounds used: the same decoder)
+ImageRGB8 decode_png(const uint8_t* data, size_t size);
 
 }  // namespace rt

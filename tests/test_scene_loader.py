@@ -70,15 +70,15 @@ BASE = """{
   camera: {lookFrom: [0,0,-5], lookAt: [0,0,0], directionUp: [0,1,0], fieldOfView: 40, aspectRatio: [1,1],
            aperture: 0, distanceToFocus: 5, startTime: 0, endTime: 1},
   background: {type: "plainColour", colour: [0,0,0]},
-  textures: {t: {type: "solidColour", colour: [1,1,1]}},
+  textures: {t: {type: "solidColour", colour: [1,1,1]} TEXS},
   materials: {m: {type: "lambertian", texture: "t"} MATS},
   objects: {OBJS},
   world: [WORLD],
 }"""
 
 
-def scene_text(objs='s: {type: "sphere", centre: [0,0,0], radius: 1, material: "m"}', world='"s"', mats=""):
-    return BASE.replace("OBJS", objs).replace("WORLD", world).replace("MATS", mats)
+def scene_text(objs='s: {type: "sphere", centre: [0,0,0], radius: 1, material: "m"}', world='"s"', mats="", texs=""):
+    return BASE.replace("OBJS", objs).replace("WORLD", world).replace("MATS", mats).replace("TEXS", texs)
 
 
 def test_json5_features(rt):
@@ -173,6 +173,191 @@ def test_jpeg_decoder_against_pil(rt):
     diff = np.abs(got - want)
     # another decoder may differ by an LSB or two per channel (IDCT / colour rounding): parity unpinned
     assert diff.max() <= 3 and diff.mean() < 0.5
+
+
+def _texels(rt, path, shape):
+    """The RGB8 texels the loader decodes `path` to (through an imageTexture of a scene), as an array of `shape`."""
+    text = scene_text(objs='s: {type: "sphere", centre: [0,0,0], radius: 1, material: "p"}', world='"s"',
+                      texs=', i: {type: "imageTexture", filename: "%s"}' % path, mats=', p: {type: "lambertian", texture: "i"}')
+    sc = rt.Scene.from_text(text)
+    n = int(np.prod(shape))
+    assert sc.counts()["texels"] == n
+    raw = (C.c_uint64 * 24).from_address(sc.desc_ptr)
+    return np.ctypeslib.as_array((C.c_uint8 * n).from_address(raw[22])).reshape(shape).copy()
+
+
+def _picture(h, w, seed=3):
+    y, x = np.mgrid[0:h, 0:w]
+    rng = np.random.default_rng(seed)
+    img = np.stack([128 + 100 * np.sin(x / 7.0 + y / 13.0), 128 + 90 * np.cos(x / 5.0) * np.sin(y / 9.0), (x * 3 + y * 5) % 256], axis=2)
+    img += rng.normal(scale=6.0, size=img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_png_textures_decode_exactly(rt, tmp_path):
+    # image 0.23 decodes whatever the file is (src/textures.rs:32-36) and into_rgb8() drops alpha, replicates grey and
+    # narrows 16-bit samples; PNG is lossless, so the texels must be PIL's (16-bit: (x + 128) / 257, stated in image_io.cpp)
+    from PIL import Image
+
+    img = _picture(37, 53)
+    cases = {
+        "rgb.png": Image.fromarray(img),
+        "rgba.png": Image.fromarray(np.dstack([img, 255 - img[:, :, :1]])),
+        "grey.png": Image.fromarray(img[:, :, 0]),
+        "grey_alpha.png": Image.fromarray(np.dstack([img[:, :, 0], img[:, :, 1]]), mode="LA"),
+        "palette.png": Image.fromarray(img).quantize(200),
+        "palette16.png": Image.fromarray(img).quantize(16),
+        "palette4.png": Image.fromarray(img).quantize(4),
+        "bilevel.png": Image.fromarray(img[:, :, 0]).convert("1"),
+    }
+    for name, im in cases.items():
+        path = str(tmp_path / name)
+        im.save(path, optimize=name.startswith("pal"))
+        want = np.asarray(Image.open(path).convert("RGB"))
+        assert np.array_equal(_texels(rt, path, want.shape), want), name
+    # interlaced (Adam7), every filter type, several IDAT chunks: written by hand below since PIL writes neither
+    import struct
+    import zlib
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+
+    h, w = img.shape[:2]
+    # non-interlaced, filter types 0-4 cycling over the rows
+    rows, prev = [], np.zeros(w * 3, dtype=np.int32)
+    for y in range(h):
+        cur = img[y].reshape(-1).astype(np.int32)
+        f = y % 5
+        a = np.concatenate([np.zeros(3, dtype=np.int32), cur[:-3]])
+        c = np.concatenate([np.zeros(3, dtype=np.int32), prev[:-3]])
+        if f == 0:
+            pred = 0
+        elif f == 1:
+            pred = a
+        elif f == 2:
+            pred = prev
+        elif f == 3:
+            pred = (a + prev) // 2
+        else:
+            pa, pb, pc = np.abs(prev - c), np.abs(a - c), np.abs(a + prev - 2 * c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        rows.append(bytes([f]) + ((cur - pred) % 256).astype(np.uint8).tobytes())
+        prev = cur
+    z = zlib.compress(b"".join(rows), 6)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"gAMA", struct.pack(">I", 45455)) + \
+        chunk(b"IDAT", z[:100]) + chunk(b"IDAT", z[100:]) + chunk(b"IEND", b"")
+    path = str(tmp_path / "filters.png")
+    open(path, "wb").write(png)
+    assert np.array_equal(np.asarray(Image.open(path).convert("RGB")), img)      # the hand-written file is a valid PNG
+    assert np.array_equal(_texels(rt, path, img.shape), img)
+    # Adam7: the seven passes, filter 0
+    x0, y0, dx, dy = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+    data = b""
+    for p in range(7):
+        sub = img[y0[p]::dy[p], x0[p]::dx[p]]
+        if sub.size:
+            data += b"".join(b"\x00" + sub[r].tobytes() for r in range(sub.shape[0]))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(data)) + chunk(b"IEND", b"")
+    path = str(tmp_path / "adam7.png")
+    open(path, "wb").write(png)
+    assert np.array_equal(np.asarray(Image.open(path).convert("RGB")), img)
+    assert np.array_equal(_texels(rt, path, img.shape), img)
+    # 16-bit RGB: narrowed by (x + 128) / 257
+    wide = (img.astype(np.uint32) * 257 + np.arange(w, dtype=np.uint32)[None, :, None] % 200).astype(">u2")
+    data = b"".join(b"\x00" + wide[r].tobytes() for r in range(h))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(data)) + chunk(b"IEND", b"")
+    path = str(tmp_path / "rgb16.png")
+    open(path, "wb").write(png)
+    assert np.array_equal(_texels(rt, path, img.shape), ((wide.astype(np.uint32) + 128) // 257).astype(np.uint8))
+
+
+def test_malformed_png_textures_are_errors_not_faults(rt, tmp_path):
+    from PIL import Image
+
+    good = tmp_path / "good.png"
+    Image.fromarray(_picture(19, 23)).save(str(good))
+    data = good.read_bytes()
+    text = scene_text(objs='s: {type: "sphere", centre: [0,0,0], radius: 1, material: "p"}', world='"s"',
+                      texs=', i: {type: "imageTexture", filename: "%s"}', mats=', p: {type: "lambertian", texture: "i"}')
+    bad = tmp_path / "bad.png"
+    rng = np.random.default_rng(11)
+    cases = [data[:k] for k in (0, 4, 8, 20, 33, 40, len(data) // 2, len(data) - 5)]
+    for _ in range(200):   # random byte flips: a CRC, a length, the zlib stream, the header ...
+        b = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(8, len(b)))] = int(rng.integers(0, 256))
+        cases.append(bytes(b))
+    errors = 0
+    for c in cases:
+        bad.write_bytes(c)
+        try:
+            rt.Scene.from_text(text % bad)
+        except rt.RtError as e:
+            assert e.code == -4
+            errors += 1
+    assert errors >= len(cases) - 5   # (a flip inside an ancillary chunk's body with its CRC is still an error; only a no-op flip decodes)
+
+
+def test_progressive_and_subsampled_jpeg_textures(rt, tmp_path):
+    # progressive (SOF2) files, 4:2:2 (h2v1) and 4:2:0 (h2v2) chroma, restart intervals, grey: against PIL / libjpeg within the
+    # tolerance test_jpeg_decoder_against_pil states (another IDCT and rounding; the up-sampling filter is jpeg-decoder's triangle,
+    # libjpeg's "fancy" one differs in the last bit) - unpinned by the reference, which holds no decoded texel
+    from PIL import Image
+
+    img = _picture(75, 101)
+    smooth = (np.stack(np.meshgrid(np.linspace(20, 230, 101), np.linspace(40, 200, 75)), axis=2).sum(axis=2) / 2)[:, :, None].repeat(3, axis=2).astype(np.uint8)
+    smooth[:, :, 1] = 255 - smooth[:, :, 1]
+    for pic_name, pic in (("noisy", img), ("smooth", smooth)):
+        for name, kw in {"prog444": dict(progressive=True, subsampling=0), "prog422": dict(progressive=True, subsampling=1),
+                         "prog420": dict(progressive=True, subsampling=2), "base422": dict(subsampling=1), "base420": dict(subsampling=2),
+                         "base444_opt": dict(subsampling=0, optimize=True)}.items():
+            path = str(tmp_path / f"{pic_name}_{name}.jpg")
+            Image.fromarray(pic).save(path, quality=90, **kw)
+            want = np.asarray(Image.open(path).convert("RGB"), dtype=np.int32)
+            got = _texels(rt, path, want.shape).astype(np.int32)
+            diff = np.abs(got - want)
+            limit = 3 if "444" in name else 24   # subsampled: the two decoders' chroma filters differ at sharp colour edges
+            assert diff.max() <= limit and diff.mean() < (0.5 if "444" in name else 1.5), (pic_name, name, diff.max(), diff.mean())
+    path = str(tmp_path / "grey_prog.jpg")
+    Image.fromarray(img[:, :, 0]).save(path, quality=85, progressive=True)
+    want = np.asarray(Image.open(path).convert("RGB"), dtype=np.int32)
+    assert np.abs(_texels(rt, path, want.shape).astype(np.int32) - want).max() <= 2
+
+
+def test_h2v1_upsampling_is_the_triangle_filter(rt, tmp_path):
+    # the filter itself, on a file whose chroma plane is known: two flat chroma halves; jpeg-decoder's h2v1 up-sampler gives
+    # (3 near + far + 2) >> 2 at the seam and the plane's own values elsewhere
+    from PIL import Image
+
+    pic = np.zeros((16, 32, 3), dtype=np.uint8)
+    pic[:, :16] = (200, 60, 60)
+    pic[:, 16:] = (60, 60, 200)
+    path = str(tmp_path / "seam.jpg")
+    Image.fromarray(pic).save(path, quality=100, subsampling=1)
+    got = _texels(rt, path, pic.shape).astype(np.int32)
+    # away from the seam the halves are flat; next to it the chroma is a 3:1 blend: monotone from one half to the other
+    assert np.abs(got[:, :12] - pic[:, :12].astype(np.int32)).max() <= 4 and np.abs(got[:, 20:] - pic[:, 20:].astype(np.int32)).max() <= 4
+    red = got[8, 12:20, 0]
+    assert np.all(np.diff(red) <= 2) and red[0] > red[-1] + 100
+
+
+def test_bmp_and_pnm_textures(rt, tmp_path):
+    from PIL import Image
+
+    img = _picture(21, 34)
+    for name, im in {"a.bmp": Image.fromarray(img), "pal.bmp": Image.fromarray(img).quantize(64), "rgba.bmp": Image.fromarray(np.dstack([img, img[:, :, :1]]))}.items():
+        path = str(tmp_path / name)
+        im.save(path)
+        want = np.asarray(Image.open(path).convert("RGB"))
+        assert np.array_equal(_texels(rt, path, want.shape), want), name
+    (tmp_path / "g.pgm").write_bytes(b"P5\n# grey\n34 21\n255\n" + img[:, :, 0].tobytes())
+    assert np.array_equal(_texels(rt, str(tmp_path / "g.pgm"), img.shape), img[:, :, :1].repeat(3, axis=2))
+    (tmp_path / "t.ppm").write_text("P3\n2 2\n15\n15 0 0  0 15 0\n0 0 15  15 15 15\n")
+    assert _texels(rt, str(tmp_path / "t.ppm"), (2, 2, 3)).tolist() == [[[255, 0, 0], [0, 255, 0]], [[0, 0, 255], [255, 255, 255]]]
+    (tmp_path / "x.gif").write_bytes(b"GIF89a" + bytes(40))
+    with pytest.raises(rt.RtError) as e:
+        _texels(rt, str(tmp_path / "x.gif"), (1,))
+    assert "unsupported image format" in e.value.message
 
 
 def test_split_samples():
