@@ -4,6 +4,7 @@ the host side (JSON5 scene files -> flattened arrays) behaves like config::load_
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -406,6 +407,16 @@ class _Triangle(C.Structure):
                 ("material", C.c_int32), ("owner", C.c_int32), ("sub", C.c_int32), ("pad", C.c_int32)]
 
 
+class _Plane(C.Structure):
+    _fields_ = [("point", C.c_double * 3), ("vec1", C.c_double * 3), ("vec2", C.c_double * 3), ("normal", C.c_double * 3),
+                ("uv_repeat", C.c_double), ("material", C.c_int32), ("owner", C.c_int32)]
+
+
+class _Medium(C.Structure):
+    _fields_ = [("neg_inv_density", C.c_double), ("boundary_object", C.c_int32), ("material", C.c_int32), ("owner", C.c_int32),
+                ("rng_key", C.c_uint32)]
+
+
 class _Image(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("texel_offset", C.c_uint64)]
 
@@ -421,7 +432,7 @@ class _Sky(C.Structure):
 
 
 _ARRAYS = [("nodes", None), ("objects", _Object), ("xforms", _Xform), ("spheres", _Sphere), ("moving_spheres", None),
-           ("rects", _Rect), ("triangles", _Triangle), ("planes", None), ("media", None), ("materials", _Material),
+           ("rects", _Rect), ("triangles", _Triangle), ("planes", _Plane), ("media", _Medium), ("materials", _Material),
            ("images", _Image), ("texels", C.c_uint8), ("top_list", C.c_int32)]
 
 
@@ -568,3 +579,195 @@ def test_obj_faces_flatten_to_the_vertices_written_by_hand(rt, tmp_path):
     # triangle 2 has no normal index: unit(cross(vec1, vec2))
     n = np.cross([2.0, 0.0, -1.0], [0.0, -3.0, -1.0])
     assert np.allclose(tuple(t2.normal), n / np.linalg.norm(n), atol=1e-15)
+
+
+# ---- the same independent check for the other example scenes (the oracle shares scene_config.cpp with the product, so
+# only numbers worked out by hand from the .json5 text and the reference's constructors can see a wrong rule in that layer)
+RT_TOP_BVH = -1
+LAMB, METAL, GLASS, LIGHT, ISO, CHECK = 0, 1, 2, 3, 4, 5
+
+
+def _spot_matrix(look_from, look_at):
+    """world -> object rotation of Spotlight::new (src/objects.rs:665-700): Translate(RotateY(RotateZ(prim, t1), t2), from) with
+    t1 = -acos(dot((0,1,0), unit(dir))), t2 = acos(dot((1,0,0), unit((dir.x, 0, dir.z)))) * -signum(dir.z), dir = at - from;
+    forward maps RotateZ: x' = s y + c x, y' = c y - s x; RotateY: x' = c x - s z, z' = s x + c z (src/transforms.rs:194-203, 285-294)."""
+    d = np.array(look_at, dtype=float) - np.array(look_from, dtype=float)
+    t1 = -np.arccos(d[1] / np.linalg.norm(d))
+    t2 = np.arccos(d[0] / np.hypot(d[0], d[2])) * -np.copysign(1.0, d[2])
+    c1, s1, c2, s2 = np.cos(t1), np.sin(t1), np.cos(t2), np.sin(t2)
+    rz = np.array([[c1, s1, 0], [-s1, c1, 0], [0, 0, 1]])
+    ry = np.array([[c2, 0, -s2], [0, 1, 0], [s2, 0, c2]])
+    return rz @ ry, d / np.linalg.norm(d)
+
+
+def _check_spotlight(d, o, look_from, look_at, length, width, light):
+    assert (o.kind, o.count) == (2, 5) and o.xform >= 0
+    h = width / 2.0
+    want = [(2, -h, 1, -h, h, -length, 0.0), (2, h, 0, -h, h, -length, 0.0), (1, -length, 1, -h, h, -h, h),
+            (0, -h, 1, -length, 0.0, -h, h), (0, h, 0, -length, 0.0, -h, h)]
+    for k, w in enumerate(want):
+        p = d["rects"][o.first + k]
+        assert (p.axis, p.k, p.facing_positive, p.a0, p.a1, p.b0, p.b1) == w and p.sub == k
+        pm = d["materials"][p.material]
+        assert (pm.type, tuple(pm.colour)) == ((LIGHT, tuple(light)) if k == 2 else (LAMB, (0.0, 0.0, 0.0)))
+    mat, unit_dir = _spot_matrix(look_from, look_at)
+    x = d["xforms"][o.xform]
+    assert np.allclose(np.array(x.m).reshape(3, 3), mat, rtol=0, atol=1e-14)
+    assert np.allclose(np.array(x.b), -mat @ np.array(look_from, dtype=float), rtol=0, atol=1e-10)
+    assert np.allclose(mat.T @ np.array([0, 1.0, 0]), unit_dir, atol=1e-12)   # the open end looks from lookFrom towards lookAt
+
+
+def _check_block(d, o, lo, hi, material):
+    # Block::new (src/objects.rs:149-168): XY@zmin(+), XY@zmax(-), XZ@ymin(+), XZ@ymax(-), YZ@xmin(+), YZ@xmax(-)
+    assert (o.kind, o.count) == (2, 6)
+    (x0, y0, z0), (x1, y1, z1) = lo, hi
+    want = [(2, z0, 1, x0, x1, y0, y1), (2, z1, 0, x0, x1, y0, y1), (1, y0, 1, x0, x1, z0, z1), (1, y1, 0, x0, x1, z0, z1),
+            (0, x0, 1, y0, y1, z0, z1), (0, x1, 0, y0, y1, z0, z1)]
+    for k, w in enumerate(want):
+        q = d["rects"][o.first + k]
+        assert (q.axis, q.k, q.facing_positive, q.a0, q.a1, q.b0, q.b1) == w and q.sub == k
+        m = d["materials"][q.material]
+        assert (m.type, m.image) == material[:2] and np.allclose(tuple(m.colour) if material[2] is not None else 0, material[2] if material[2] is not None else 0)
+
+
+def test_two_spheres_flattens_to_the_values_written_by_hand(rt):
+    sc = rt.Scene.load(scene_path("two_spheres"), ROOT)
+    d = _desc(sc)
+    objs, mats = d["objects"], d["materials"]
+    # world: sun, floor, floorGlass, sphere, sphereGlass, sphere2; the planes have no box and follow the BVH in the top-level list
+    # (BVHNode::from_vec, src/hitting.rs:188-194), in world order
+    tops = list(d["top_list"])
+    assert tops[0] == RT_TOP_BVH and [objs[t].world_index for t in tops[1:]] == [1, 2] and all(objs[t].kind == 4 for t in tops[1:])
+    for wi, centre, radius, mtype, mparam in ((0, (4000.0, 0.0, 0.0), 1000.0, LIGHT, None), (3, (-250.0, 100.0, 50.0), 99.5, LAMB, None),
+                                              (4, (-250.0, 100.0, 50.0), 100.0, GLASS, 1.5), (5, (0.0, 100.0, 0.0), 100.0, GLASS, 1.5)):
+        o = _one(objs, world_index=wi)
+        s = d["spheres"][o.first]
+        assert (o.kind, o.xform) == (0, -1) and tuple(s.centre) == centre and s.radius == radius and mats[s.material].type == mtype
+        if mparam is not None:
+            assert mats[s.material].param == mparam
+    assert tuple(mats[d["spheres"][_one(objs, world_index=0).first].material].colour) == (150.0, 55.0, 0.0)
+    # Plane::new (src/objects.rs:577-597): vec1 = unit(b - a); normal = unit(vec1 x (c - a)); vec2 = normal x vec1
+    # floor: a = (0,-1,0), b = (0,-1,1), c = (1,-1,0): vec1 = (0,0,1), normal = (0,0,1) x (1,0,0) = (0,1,0), vec2 = (0,1,0) x (0,0,1) = (1,0,0)
+    for wi, y, repeat, mtype in ((1, -1.0, 400.0, CHECK), (2, 0.0, 80.0, GLASS)):
+        p = d["planes"][_one(objs, world_index=wi).first]
+        assert tuple(p.point) == (0.0, y, 0.0) and tuple(p.vec1) == (0.0, 0.0, 1.0) and tuple(p.normal) == (0.0, 1.0, 0.0) and tuple(p.vec2) == (1.0, 0.0, 0.0)
+        assert p.uv_repeat == repeat and mats[p.material].type == mtype
+    chk = mats[d["planes"][_one(objs, world_index=1).first].material]
+    assert chk.param == 2.0 and (mats[chk.odd].type, mats[chk.even].type) == (METAL, LAMB) and mats[chk.odd].param == 0.0
+    assert tuple(mats[chk.odd].colour) == (0.73, 0.73, 0.73)
+    # camera (src/camera.rs:25-66): w = unit(from - at) = (0, 300, -800) / sqrt(730000); u = unit(up x w) = (-1, 0, 0); v = w x u
+    cam = d["camera"]
+    w = np.array([0.0, 300.0, -800.0]) / np.sqrt(730000.0)
+    assert np.allclose(cam.u, [-1.0, 0.0, 0.0], atol=1e-15) and np.allclose(cam.v, [0.0, -w[2], w[1]], atol=1e-15)
+    vh = 2.0 * np.tan(np.radians(40.0) / 2.0)
+    assert cam.lens_radius == 0.05 and np.allclose(cam.horizontal, [-100.0 * 1.6 * vh, 0, 0], rtol=1e-14)
+    assert np.allclose(cam.horizontal, [-116.4704749649, 0, 0], rtol=1e-10)   # 160 x 2 tan(20 deg)
+    assert np.allclose(cam.vertical, 100.0 * vh * np.array([0.0, -w[2], w[1]]), rtol=1e-14)
+    llc = np.array([-100.0, 400.0, -800.0]) - np.array(cam.horizontal) / 2 - np.array(cam.vertical) / 2 - 100.0 * w
+    assert np.allclose(cam.lower_left_corner, llc, rtol=1e-13)
+    sky = d["sky"]
+    assert sky.gradient == 1 and np.allclose(sky.unit_dir, np.array([1.0, -0.2, 0.0]) / np.sqrt(1.04), atol=1e-15)
+    assert tuple(sky.colour0) == (0.0, 0.0, 0.0) and tuple(sky.colour1) == (3.0, 1.7, 0.4)
+
+
+def test_knight_flattens_to_the_values_written_by_hand(rt):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gen_knight
+
+    gen_knight.ensure(os.path.join(ROOT, "examples", "knight.obj"))
+    sc = rt.Scene.load(scene_path("knight"), ROOT)
+    d = _desc(sc)
+    objs, mats = d["objects"], d["materials"]
+    # world: knight (translate of the mesh), board (plane), spotlight; "beacon" is defined but not in `world` and must not be flattened
+    tops = list(d["top_list"])
+    assert tops[0] == RT_TOP_BVH and len(tops) == 2 and objs[tops[1]].world_index == 1
+    assert len(list(objs)) == 3 and sc.counts()["rects"] == 5
+    k = _one(objs, world_index=0)
+    x = d["xforms"][k.xform]
+    # Translate::hit moves the ray by -offset (src/transforms.rs:22-23): world -> object p' = p - (-11, -16, 0.001)
+    assert k.kind == 5 and np.array_equal(np.array(x.m).reshape(3, 3), np.eye(3)) and tuple(x.b) == (11.0, 16.0, -0.001)
+    tri = d["triangles"][0]
+    assert mats[tri.material].type == GLASS and mats[tri.material].param == 1.5 and sc.counts()["triangles"] > 50000
+    # board: a = (0,0,0), b = (1,0,0), c = (0,1,0): vec1 = (1,0,0), normal = (1,0,0) x (0,1,0) = (0,0,1), vec2 = (0,0,1) x (1,0,0) = (0,1,0)
+    p = d["planes"][_one(objs, world_index=1).first]
+    assert tuple(p.point) == (0.0, 0.0, 0.0) and tuple(p.vec1) == (1.0, 0.0, 0.0) and tuple(p.normal) == (0.0, 0.0, 1.0) and tuple(p.vec2) == (0.0, 1.0, 0.0)
+    chk = mats[p.material]
+    assert p.uv_repeat == 12.0 and (chk.type, chk.param) == (CHECK, 2.0) and (mats[chk.odd].type, mats[chk.even].type) == (METAL, LAMB)
+    assert tuple(mats[chk.even].colour) == (0.05, 0.05, 0.05)
+    _check_spotlight(d, _one(objs, world_index=2), (-30.0, -30.0, 15.0), (0.0, 0.0, 5.0), 30.0, 10.0, (60.0, 60.0, 2.0))
+    # the angles themselves: dir = (30, 30, -10); t1 = -acos(30 / sqrt(1900)), t2 = +acos(30 / sqrt(1000)) (dir.z < 0)
+    mat, _ = _spot_matrix((-30.0, -30.0, 15.0), (0.0, 0.0, 5.0))
+    t1, t2 = -0.8117261175, 0.3217505544
+    assert np.allclose(mat, np.array([[np.cos(t1), np.sin(t1), 0], [-np.sin(t1), np.cos(t1), 0], [0, 0, 1]]) @
+                       np.array([[np.cos(t2), 0, -np.sin(t2)], [0, 1, 0], [np.sin(t2), 0, np.cos(t2)]]), atol=1e-9)
+    cam = d["camera"]
+    assert tuple(cam.origin) == (-17.0, -8.0, 15.0) and cam.lens_radius == 0.0
+    wv = np.array([-17.0, -8.0, 10.0]) / np.sqrt(453.0)              # unit(from - at)
+    u = np.cross([0.0, 0.0, 1.0], wv)
+    u /= np.linalg.norm(u)
+    assert np.allclose(cam.u, u, atol=1e-15) and np.allclose(cam.v, np.cross(wv, u), atol=1e-15)
+    assert np.allclose(cam.horizontal, 75.0 * 2.0 * np.tan(np.radians(20.0)) * u, rtol=1e-14)
+    assert d["sky"].gradient == 0 and tuple(d["sky"].colour) == (0.4, 0.4, 0.6)
+
+
+def test_blocks_ball_flattens_to_the_values_written_by_hand(rt):
+    sc = rt.Scene.load(scene_path("blocks_ball"), ROOT)
+    d = _desc(sc)
+    objs, mats = d["objects"], d["materials"]
+    c = sc.counts()
+    # mist (medium) + its boundary block, ball, light (5 panes), 20 x 20 blocks
+    assert (c["objects"], c["rects"], c["spheres"], c["media"], c["planes"]) == (404, 6 + 5 + 2400, 1, 1, 0)
+    assert list(d["top_list"]) == [RT_TOP_BVH]
+    mist = _one(objs, world_index=0)
+    md = d["media"][mist.first]
+    assert mist.kind == 6 and md.neg_inv_density == -1.0 / 0.0003 and (mats[md.material].type, tuple(mats[md.material].colour)) == (ISO, (1.0, 1.0, 1.0))
+    bound = objs[md.boundary_object]
+    assert bound.world_index == -1 and bound.xform == -1
+    _check_block(d, bound, (-2000.0, -2000.0, -2000.0), (2000.0, 2000.0, 2000.0), (ISO, -1, (1.0, 1.0, 1.0)))
+    ball = d["spheres"][_one(objs, world_index=1).first]
+    assert tuple(ball.centre) == (310.0, 200.0, 100.0) and ball.radius == 100.0 and (mats[ball.material].type, mats[ball.material].param) == (GLASS, 1.5)
+    _check_spotlight(d, _one(objs, world_index=2), (750.0, 330.0, 200.0), (310.0, 150.0, 100.0), 600.0, 120.0, (80.0, 80.0, 80.0))
+    # dir = (-440, -180, -100): t1 = -acos(-180 / sqrt(236000)) = -1.950378..., t2 = +acos(-440 / sqrt(203600)) = 2.918083... (dir.z < 0)
+    mat, _ = _spot_matrix((750.0, 330.0, 200.0), (310.0, 150.0, 100.0))
+    t1, t2 = -np.arccos(-180.0 / np.sqrt(236000.0)), np.arccos(-440.0 / np.sqrt(203600.0))
+    assert abs(t1 + 1.9503779) < 1e-6 and abs(t2 - 2.9180836) < 1e-6
+    assert np.allclose(mat[1], [-np.sin(t1) * np.cos(t2), np.cos(t1), np.sin(t1) * np.sin(t2)], atol=1e-14)
+    # block_i_j sits at world index 3 + 20 i + j with corners (-1000 + 100 i, -1, -1000 + 100 j) .. (+100, height, +100):
+    # block_0_0 is 50 high, block_0_3 79, block_12_10 56 (examples/blocks_ball.json5:70)
+    for (i, j), height in (((0, 0), 50.0), ((0, 3), 79.0), ((12, 10), 56.0)):
+        o = _one(objs, world_index=3 + 20 * i + j)
+        assert o.xform == -1
+        _check_block(d, o, (-1000.0 + 100 * i, -1.0, -1000.0 + 100 * j), (-900.0 + 100 * i, height, -900.0 + 100 * j), (LAMB, -1, (0.48, 0.83, 0.53)))
+    cam = d["camera"]
+    assert tuple(cam.origin) == (478.0, 378.0, -600.0) and cam.lens_radius == 0.0
+    assert np.allclose(np.linalg.norm(cam.horizontal), 300.0 * (16.0 / 9.0) * 2.0 * np.tan(np.radians(20.0)), rtol=1e-14)
+    assert sc.image_height(600) == 338
+
+
+def test_blue_ball_flattens_to_the_values_written_by_hand(rt):
+    sc = rt.Scene.load(scene_path("blue_ball"), ROOT)
+    d = _desc(sc)
+    objs, mats = d["objects"], d["materials"]
+    c = sc.counts()
+    # six walls + ONE Block shared by the world entry `tallBlock` and by the boundary of `smoke` (true instancing); three spheres
+    assert (c["rects"], c["spheres"], c["media"], c["objects"]) == (12, 3, 1, 12)
+    back = _one(d["rects"], axis=2, k=555.0)
+    assert mats[back.material].type == GLASS and back.facing_positive == 0       # the back wall is glass here
+    tall = _one(objs, world_index=6)
+    smoke = _one(objs, world_index=7)
+    md = d["media"][smoke.first]
+    bound = objs[md.boundary_object]
+    assert smoke.kind == 6 and md.neg_inv_density == -1.0 / 0.0013 and mats[md.material].type == ISO
+    assert bound.world_index == -1 and bound.first == tall.first and bound.count == 6     # the same six rects
+    _check_block(d, tall, (0.0, 0.1, 0.0), (165.0, 330.0, 165.0), (GLASS, -1, None))
+    th = np.radians(15.0)
+    m = np.array([[np.cos(th), 0, -np.sin(th)], [0, 1, 0], [np.sin(th), 0, np.cos(th)]])      # RotateY forward map (src/transforms.rs:194-203)
+    for o in (tall, bound):
+        x = d["xforms"][o.xform]
+        assert np.allclose(np.array(x.m).reshape(3, 3), m, rtol=0, atol=1e-15)
+        assert np.allclose(np.array(x.b), -m @ np.array([285.0, 0.0, 295.0]), rtol=0, atol=1e-12)
+    for wi, centre, radius, mtype in ((8, (300.0, 100.1, 50.0), 100.0, GLASS), (9, (160.0, 120.1, 350.0), 120.0, GLASS), (10, (160.0, 120.1, 350.0), 110.0, LAMB)):
+        s = d["spheres"][_one(objs, world_index=wi).first]
+        assert tuple(s.centre) == centre and s.radius == radius and mats[s.material].type == mtype
+    light = _one(d["rects"], axis=1, k=554.0)
+    assert (light.a0, light.a1, light.b0, light.b1, light.facing_positive) == (214.0, 343.0, 227.0, 332.0, 0) and mats[light.material].type == LIGHT
