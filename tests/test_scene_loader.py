@@ -727,10 +727,10 @@ def test_blocks_ball_flattens_to_the_values_written_by_hand(rt):
     ball = d["spheres"][_one(objs, world_index=1).first]
     assert tuple(ball.centre) == (310.0, 200.0, 100.0) and ball.radius == 100.0 and (mats[ball.material].type, mats[ball.material].param) == (GLASS, 1.5)
     _check_spotlight(d, _one(objs, world_index=2), (750.0, 330.0, 200.0), (310.0, 150.0, 100.0), 600.0, 120.0, (80.0, 80.0, 80.0))
-    # dir = (-440, -180, -100): t1 = -acos(-180 / sqrt(236000)) = -1.950378..., t2 = +acos(-440 / sqrt(203600)) = 2.918083... (dir.z < 0)
+    # dir = (-440, -180, -100): t1 = -acos(-180 / sqrt(236000)) = -1.950370, t2 = +acos(-440 / sqrt(203600)) = 2.918116 (dir.z < 0)
     mat, _ = _spot_matrix((750.0, 330.0, 200.0), (310.0, 150.0, 100.0))
     t1, t2 = -np.arccos(-180.0 / np.sqrt(236000.0)), np.arccos(-440.0 / np.sqrt(203600.0))
-    assert abs(t1 + 1.9503779) < 1e-6 and abs(t2 - 2.9180836) < 1e-6
+    assert abs(t1 + 1.9503696) < 1e-6 and abs(t2 - 2.9181161) < 1e-6
     assert np.allclose(mat[1], [-np.sin(t1) * np.cos(t2), np.cos(t1), np.sin(t1) * np.sin(t2)], atol=1e-14)
     # block_i_j sits at world index 3 + 20 i + j with corners (-1000 + 100 i, -1, -1000 + 100 j) .. (+100, height, +100):
     # block_0_0 is 50 high, block_0_3 79, block_12_10 56 (examples/blocks_ball.json5:70)
