@@ -1050,7 +1050,11 @@ __device__ RT_MEDIUM_ATTR bool medium_hit(const DScene<T>& S, const DObject ob, 
     T t1, t2;
     // (the second query runs only in the lanes whose first one hit, so it is not wave-uniform)
     if (!boundary_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, -inf, inf, st, sp, shift, path, depth, &t1)) return false;
-    if (!boundary_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, t1 + (T)0.0001, inf, st, sp, shift, path, depth, &t2)) return false;
+    T beyond = t1 + (T)0.0001;
+    // (fast mode: 0.0001 is below f32 resolution from |t| ~ 800 on, and a query from t1 itself finds the first crossing again - the
+    // mist of blocks_ball, whose boundary is 2000 units away, vanished for a third of the rays: at least two ulps beyond t1)
+    if constexpr (sizeof(T) == 4) beyond = fmaxf(beyond, t1 + fabsf(t1) * 2.4e-7f);
+    if (!boundary_hit<T, UNIFORM, FEAT>(S, md.boundary_object, r, beyond, inf, st, sp, shift, path, depth, &t2)) return false;
     if (t1 < min_dist) t1 = min_dist;
     if (t2 > max_dist) t2 = max_dist;
     if (t1 >= t2) return false;

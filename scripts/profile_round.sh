@@ -35,6 +35,11 @@ bench)
     done
   done
   timeout -k 10 500 $B --steps 3 --warmup 1 --scene knight --triangles 1000000 > $O/bench_knight_1m.json
+  # the fast mode (same kernels in f32), its throughput next to its measured ID-mismatch rate (scripts/measure_f32.py)
+  for s in cornell knight blocks_ball; do
+    timeout -k 10 300 $B --steps 5 --warmup 1 --scene $s --precision f32 --no-cpu-baseline > $O/bench_${s}_f32.json
+  done
+  timeout -k 10 300 python3 $R/scripts/measure_f32.py > $O/f32_mode.json
   ;;
 stats)
   for s in cornell knight blocks_ball globe two_spheres; do

@@ -559,3 +559,27 @@ def test_rays_that_start_far_outside_the_scene(gpu_scenes, oracle_scenes, name):
     assert np.all(same[hit & ~tie])
     # (a chain of transforms is one rigid map on the GPU and one re-normalisation per level in the reference: last bits)
     assert np.allclose(got["t"][hit & same], want["t"][hit & same], rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_fast_mode_hit_ids_against_the_oracle(gpu_scenes, rt, name):
+    # RT_PRECISION_F32 is the declared fast mode: the same kernels in f32, compared statistically only.  SURVEY.md section 7 asks for
+    # its ID-mismatch rate to be measured and reported (profiles/r03/f32_mode.json): this bounds it.  On the golden rays
+    # (the oracle's f64 records) rays that are not exact ties may name another primitive only where f32 cannot tell two candidates
+    # apart; measured (scripts/measure_f32.py): no ID mismatch and no hit / miss flip on any of the six scenes, on the golden rays and on a
+    # 160-px frame of primary rays alike; t within 2e-3 relative at worst, 1e-5 at the 99th percentile (far hits at f32 resolution).
+    # (Before round 3 the mist of blocks_ball vanished for 6 % of the rays in f32: the medium's `+ 0.0001` is below f32 resolution.)
+    g = np.load(os.path.join(GOLDEN, name + "_rays.npz"))
+    _, r32 = gpu_scenes(name, precision=rt.PRECISION_F32)
+    got = r32.trace(g["rays"], seed=int(g["seed"]))
+    want = g["hits"]
+    hit = want["hit"] == 1
+    assert (got["hit"] != want["hit"]).mean() <= 0.001
+    both = hit & (got["hit"] == 1)
+    tie = tie_mask(want, want["second_t"])
+    same = (got["owner"] == want["owner"]) & (got["sub"] == want["sub"])
+    judged = both & ~tie
+    assert (judged & ~same).sum() <= 0.002 * judged.sum(), f"{(judged & ~same).sum()} of {judged.sum()} IDs differ in f32"
+    ok = both & same
+    t_err = np.abs(got["t"][ok] - want["t"][ok]) / np.maximum(np.abs(want["t"][ok]), 1e-300)
+    assert np.quantile(t_err, 0.99) <= 1e-4 and t_err.max() <= 1e-2
