@@ -364,6 +364,59 @@ struct Lane {
     }
 };
 
+// Experiment switches (A/B runs and tests; the results never depend on them - tests/test_gpu_parity.py renders every scene
+// under each).  They are read from the environment ONCE, when a context is created: no entry point looks at the
+// environment afterwards.  INTEGRATION.md lists them.
+struct Tuning {
+    int stack_cap = 0;          // RT_STACK_CAP: LDS stack entries a four-wide walk may use (0: the kernel's own)
+    bool bvh4 = true;           // RT_BVH4=0: binary walks only
+    int sah = 1;                // RT_SAH=0: the reference's grouping folded two levels into one; 2: SAH for meshes only
+    bool ordered = true;        // RT_ORDERED=0: the reference's fixed left-first order
+    int coop = 16;              // RT_COOP=n: lane groups answer a tail wave's queries while it has at most n live paths (0: never)
+    bool all_features = false;  // RT_FEATURES=all: the general four-wide kernel whatever the scene holds
+    long sweep_max = 12;        // RT_SWEEP_MAX: largest world (leaves) that is swept instead of walked
+    int refill = -1;            // RT_REFILL=n: k_extend_refill's threshold (-1: by scene)
+    size_t grid_mult = 0;       // RT_GRID_MULT: persistent blocks per CU (0: 32, or 8 per lane while two lanes run)
+    int tail_blocks = 0;        // RT_TAIL_BLOCKS: resident blocks per CU of the tail launch (0: by kind of walk)
+    uint64_t lane_min_paths = (uint64_t)8 << 20;  // RT_LANE_MIN_PATHS: paths per lane from which a second lane runs
+    bool one_lane = false;      // RT_ONE_LANE=1: one lane at a time, batches cut as usual (profiles)
+    int fuse = -1;              // RT_FUSE=0 / 1: fused per-bounce kernel off / on (-1: lean sweeps only)
+    long tail = -1;             // RT_TAIL=n: live paths at or below which the tail launch takes over (-1: by scene, 0: never)
+    int pixel_blocks = -1;      // RT_PIXEL_BLOCKS=0 rows, 1 blocks of 8 x 8 pixels, 2 forced pixels x samples (-1: by scene)
+    uint32_t runahead = 2;      // RT_RUNAHEAD: bounces enqueued beyond the last live count the host has seen
+    bool debug = false;         // RT_DEBUG: counts and layout choices on stderr
+    static Tuning from_environment() {
+        Tuning t;
+        auto num = [](const char* name, long fallback) {
+            const char* e = std::getenv(name);
+            return e && e[0] ? std::strtol(e, nullptr, 10) : fallback;
+        };
+        auto is = [](const char* name, char c) {
+            const char* e = std::getenv(name);
+            return e && e[0] == c;
+        };
+        t.stack_cap = (int)num("RT_STACK_CAP", 0);
+        t.bvh4 = !is("RT_BVH4", '0');
+        t.sah = is("RT_SAH", '0') ? 0 : is("RT_SAH", '2') ? 2 : 1;
+        t.ordered = !is("RT_ORDERED", '0');
+        t.coop = (int)std::max(0l, std::min(32l, num("RT_COOP", 16)));
+        t.all_features = is("RT_FEATURES", 'a');
+        t.sweep_max = num("RT_SWEEP_MAX", 12);
+        t.refill = (int)num("RT_REFILL", -1);
+        const long gm = num("RT_GRID_MULT", 0);
+        t.grid_mult = gm > 0 && gm <= 65536 ? (size_t)gm : 0;
+        t.tail_blocks = (int)num("RT_TAIL_BLOCKS", 0);
+        if (const char* e = std::getenv("RT_LANE_MIN_PATHS")) t.lane_min_paths = (uint64_t)std::strtoull(e, nullptr, 10);
+        t.one_lane = is("RT_ONE_LANE", '1');
+        if (const char* e = std::getenv("RT_FUSE")) t.fuse = e[0] != '0' ? 1 : 0;
+        t.tail = num("RT_TAIL", -1);
+        if (const char* e = std::getenv("RT_PIXEL_BLOCKS")) t.pixel_blocks = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
+        t.runahead = (uint32_t)std::max(1l, std::min(64l, num("RT_RUNAHEAD", 2)));
+        t.debug = std::getenv("RT_DEBUG") != nullptr;
+        return t;
+    }
+};
+
 struct EngineBase {
     virtual ~EngineBase() {}
     virtual void upload(const rt_scene_desc& d) = 0;
@@ -415,6 +468,7 @@ struct Engine : EngineBase {
     uint32_t tail_threshold_fused = 1048576u, tail_threshold_tree = 1048576u;  // live paths at or below which the tail launch takes over
     int tail_blocks_per_cu = 2;  // blocks of the tail launch that stay resident per CU (k_bounce<.., CAN_TAIL = true>: RT_TAIL_WAVES waves per SIMD)
     rt_upload_stats up_stats;
+    const Tuning tune = Tuning::from_environment();  // (once per context, here: rt_create)
     void set_launch_timing(bool on) override { time_launches = on; }
     void upload_stats(rt_upload_stats* out) override { *out = up_stats; }
 
@@ -469,35 +523,27 @@ struct Engine : EngineBase {
         // walk keeps up to 3 siblings per level on its stack, and a tree whose worst case would not fit
         // the stack (LDS class + overflow array) is not used: SAH -> folded reference tree -> binary walk.
         stack_depth = d.stack_depth;
-        S.stack_cap = 0;
-        if (const char* cap_env = std::getenv("RT_STACK_CAP")) S.stack_cap = (int32_t)std::strtol(cap_env, nullptr, 10);  // tests
+        S.stack_cap = tune.stack_cap;  // (tests)
         sah_trees = false;
         {
-            const char* e = std::getenv("RT_BVH4");
-            const char* sah_env = std::getenv("RT_SAH");
             const int lds_class = stack_depth <= 16 ? 16 : stack_depth <= 32 ? 32 : 64;
             const int lds_part = S.stack_cap > 0 && S.stack_cap < lds_class ? S.stack_cap : lds_class;
             const float pad = box_pad(d);
             S.tlas_root4 = -1;
             stack_need4 = 0;
-            for (int use_sah = (sah_env && sah_env[0] == '0') ? 0 : 1; use_sah >= 0; use_sah--) {
-                if ((e && e[0] == '0') || d.tlas_root < 0) break;
+            for (int use_sah = tune.sah == 0 ? 0 : 1; use_sah >= 0; use_sah--) {
+                if (!tune.bvh4 || d.tlas_root < 0) break;
                 std::vector<rtd::WideNode4> v;
                 int need = 0, need_world = 0;
-                // RT_BVH8=1 (experiment; needs a library whose kernels were built with -DRT_BVH8): mesh trees eight wide
-                const char* wide8_env = std::getenv("RT_BVH8");
-                const bool wide8 = wide8_env && wide8_env[0] == '1';
-                if (wide8 && !use_sah) throw RtError{RT_ERR_UNSUPPORTED, "RT_BVH8: the eight-wide trees do not fit the traversal stack"};
                 auto build = [&](int32_t root, int* need_out) {
                     int32_t r = -1;
-                    if (use_sah && wide8 && root != d.tlas_root && build_sah8(d, root, pad, v, &r, need_out)) return r;
                     if (use_sah && build_sah4(d, root, pad, v, &r, need_out)) return r;
                     return build_nodes4(d, root, pad, v, need_out);
                 };
                 std::fill(root4.begin(), root4.end(), -1);
                 {
                     const int meshes_too = use_sah;
-                    if (sah_env && sah_env[0] == '2') use_sah = 0;  // RT_SAH=2: meshes only
+                    if (tune.sah == 2) use_sah = 0;  // RT_SAH=2: meshes only
                     S.tlas_root4 = build(d.tlas_root, &need_world);
                     use_sah = meshes_too;
                 }
@@ -510,7 +556,7 @@ struct Engine : EngineBase {
                 stack_need4 = need + need_world + 3;
                 std::vector<rtd::DNode4> packed;
                 if (stack_need4 <= lds_part + RT_STACK_OVERFLOW && quantize_nodes4(v, packed)) {
-                    if (std::getenv("RT_DEBUG") && v[(size_t)S.tlas_root4].child[0] >= 0) {
+                    if (tune.debug && v[(size_t)S.tlas_root4].child[0] >= 0) {
                         const rtd::WideNode4& w = v[(size_t)v[(size_t)S.tlas_root4].child[0]];
                         for (int k = 0; k < 4; k++)
                             std::fprintf(stderr, "  world slot %d: child %d  [%g %g %g] - [%g %g %g]\n", k, w.child[k], w.lo[0][k], w.lo[1][k],
@@ -718,19 +764,17 @@ struct Engine : EngineBase {
             }
         }
         // RT_ORDERED=0 (environment) walks trees in the reference's fixed left-first order (A/B runs).
-        const char* ordered_env = std::getenv("RT_ORDERED");
-        S.ordered = !(ordered_env && ordered_env[0] == '0');
+        S.ordered = tune.ordered ? 1 : 0;
         // RT_COOP=0: the tail launch walks meshes with one lane per path throughout (A/B runs; the image is the same).
         // RT_COOP=n: groups of lanes answer a query in the tail launch while a wave has at most n live paths (0: never).
-        const char* coop_env = std::getenv("RT_COOP");
-        S.coop = coop_env ? std::max(0, std::min(32, std::atoi(coop_env))) : 16;
+        S.coop = tune.coop;
         S.coop_reserve = stack_need4;
         S.has_meshes = S.has_media = 0;
         for (uint64_t i = 0; i < d.n_objects; i++) {
             if (d.objects[i].kind == RT_OBJ_BLAS) S.has_meshes = 1;
             if (d.objects[i].kind == RT_OBJ_MEDIUM) S.has_media = 1;
         }
-        if (const char* e = std::getenv("RT_FEATURES"); e && e[0] == 'a') S.has_meshes = S.has_media = 1;  // "all": the general kernel (A/B runs, tests)
+        if (tune.all_features) S.has_meshes = S.has_media = 1;  // RT_FEATURES=all: the general kernel (A/B runs, tests)
         // A medium bounded by a medium (src/objects.rs:404-409 takes any Hittable): only the general four-wide kernel
         // compiles the nested boundary query in (FEAT_NESTED_MEDIA), so such a scene takes it whatever else it holds.
         nested_media = false;
@@ -751,7 +795,7 @@ struct Engine : EngineBase {
             S.lean = 0;
             std::memset(&small, 0, sizeof(small));
         }
-        if (std::getenv("RT_DEBUG"))
+        if (tune.debug)
             std::fprintf(stderr, "rt_upload_scene: objects %llu, stack_depth %d, four-wide %s (stack need %d, lds cap %d), sweep %d%s\n",
                          (unsigned long long)d.n_objects, stack_depth, S.nodes4 ? (sah_trees ? "sah" : "folded") : "no", stack_need4,
                          S.stack_cap, S.n_sweep, S.lean ? " lean" : "");
@@ -780,8 +824,7 @@ struct Engine : EngineBase {
         S.n_sweep = 0;
         S.lean = 0;
         if (d.tlas_root < 0) return;
-        long limit = 12;
-        if (const char* e = std::getenv("RT_SWEEP_MAX")) limit = std::strtol(e, nullptr, 10);
+        const long limit = tune.sweep_max;
         std::vector<int32_t> order, todo{d.tlas_root};
         while (!todo.empty()) {
             const rt_node& nd = d.nodes[todo.back()];
@@ -883,7 +926,7 @@ struct Engine : EngineBase {
         int refill = 0;
         if (S.nodes4 && S.n_sweep == 0 && !small.blob) {
             refill = S.has_meshes ? 0 : 64;
-            if (const char* e = std::getenv("RT_REFILL")) refill = (int)std::strtol(e, nullptr, 10);
+            if (tune.refill >= 0) refill = tune.refill;
         }
         return refill;
     }
@@ -901,12 +944,8 @@ struct Engine : EngineBase {
         // cornell 22.3 -> 21.1 ms, knight 48.6 -> 47.2, blocks_ball 20.2 -> 20.0 (4: 23.0 / 49.4 / 20.3; 16: 21.4 /
         // 47.5 / 20.1; 64: 21.1 / 48.3 / 19.9; 128: 21.2 / 49.6 / 19.9; one block per 256 rays: 22.1 / 51.4 / 19.9).
         // RT_GRID_MULT=n (environment) overrides for A/B runs.
-        static const bool grid_mult_forced = std::getenv("RT_GRID_MULT") != nullptr;
-        static const size_t per_cu = [] {
-            const char* e = std::getenv("RT_GRID_MULT");
-            const long v = e ? std::strtol(e, nullptr, 10) : 0;
-            return (size_t)(v > 0 && v <= 65536 ? v : 32);
-        }();
+        const bool grid_mult_forced = tune.grid_mult != 0;
+        const size_t per_cu = grid_mult_forced ? tune.grid_mult : 32;
         // (two lanes share the CUs: 8 per CU each measured best, knight 45.2 -> 43.8 ms, cornell 19.7 -> 19.3)
         size_t cap = (size_t)num_cus * (lanes_running > 1 && !grid_mult_forced ? 8 : per_cu);
         blocks = blocks < 1 ? 1 : blocks > cap ? cap : blocks;
@@ -915,10 +954,7 @@ struct Engine : EngineBase {
     }
     int tail_grid_for(size_t n) {  // the tail launch hands paths out from a cursor: no more blocks than stay resident (RT_TAIL_WAVES per SIMD)
         size_t blocks = (n + 255) / 256;
-        static const int env_blocks = [] {
-            const char* e = std::getenv("RT_TAIL_BLOCKS");  // A/B runs of other RT_TAIL_WAVES builds
-            return e ? (int)std::strtol(e, nullptr, 10) : 0;
-        }();
+        const int env_blocks = tune.tail_blocks;  // (A/B runs of builds with other tail_waves())
         // blocks that stay resident per CU = the waves per SIMD the scene's tail kernel is compiled for (kernels.hip, tail_waves)
         const int resident = S.n_sweep > 0 && S.lean ? 3 : S.nodes4 && S.has_meshes ? 4 : tail_blocks_per_cu;
         const size_t cap = (size_t)num_cus * (env_blocks > 0 ? env_blocks : resident);
@@ -1011,18 +1047,14 @@ struct Engine : EngineBase {
         // Lanes: a second stream pays when each lane still gets a large batch (600 px, 100 spp: cornell 20.65 -> 19.3 ms,
         // knight 46.1 -> 43.8, blocks_ball 19.5 -> 18.7; at 13 spp the halves are too small and it loses 3 - 20 %), and
         // a band that fills the path budget leaves no room for a second lane's queues.  RT_LANE_MIN_PATHS overrides.
-        static const uint64_t lane_min_paths = [] {
-            const char* e = std::getenv("RT_LANE_MIN_PATHS");
-            return e ? (uint64_t)std::strtoull(e, nullptr, 10) : (uint64_t)8 << 20;
-        }();
+        const uint64_t lane_min_paths = tune.lane_min_paths;
         // While launches are timed one lane runs: a launch's duration is then its own, not stretched by the other lane's
         // kernels on the same CUs (what the roofline of a kernel is priced with).
         const int K_untimed = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(lanes.size(), max_paths / npix),
                                                                             npix * ns / std::max<uint64_t>(1, lane_min_paths)));
         // RT_ONE_LANE=1: one lane at a time with the batches of the usual call (what launch timing does: for profiles
         // whose per-launch durations are to be a kernel's own)
-        const char* one_lane_env = std::getenv("RT_ONE_LANE");
-        const int K = fixed || time_launches || (one_lane_env && one_lane_env[0] == '1') ? 1 : K_untimed;
+        const int K = fixed || time_launches || tune.one_lane ? 1 : K_untimed;
         // (a call with launch timing runs one lane, but cuts its batches as the same call without timing would: the
         // lane's buffers then need not grow - freeing and allocating 9 GB cost the timed step of bench.py 3 ms)
         const uint64_t lane_paths = fixed ? (uint64_t)RT_NOALLOC_MAX_PATHS : std::max<uint64_t>(1, max_paths / (uint64_t)K_untimed);
@@ -1042,9 +1074,8 @@ struct Engine : EngineBase {
         // One fused launch per bounce pays off when the traversal is the lean sweep (no stack, no spills:
         // cornell 30.5 -> 25.2 ms); with a divergent tree walk the shading half runs at the walk's low
         // occupancy and loses (knight 95 -> 107 ms).  RT_FUSE=0 / 1 (environment) overrides for A/B runs.
-        const bool debug_counts = std::getenv("RT_DEBUG") != nullptr;
-        const char* fuse_env = std::getenv("RT_FUSE");
-        const bool fused = fuse_env ? fuse_env[0] != '0' : (S.n_sweep > 0 && S.lean);
+        const bool debug_counts = tune.debug;
+        const bool fused = tune.fuse >= 0 ? tune.fuse != 0 : (S.n_sweep > 0 && S.lean);
         // Paths alive at or below which the tail launch takes over (RT_TAIL=n in the environment overrides, 0: never).
         // The tail launch hands its paths out from a cursor, so it stays efficient with many more paths than are
         // resident at a time; what it saves is the wait for the slowest ray of every bounce.
@@ -1055,13 +1086,11 @@ struct Engine : EngineBase {
         // 4.7 M paths: 7.8 ms either way, 9.3 if the tail took bounce 0 too).
         uint32_t tail_threshold_late = tail_threshold;  // from the third bounce on
         if (!fused && S.nodes4 && S.has_meshes) tail_threshold_late = 4194304u;
-        if (const char* e = std::getenv("RT_TAIL")) tail_threshold = tail_threshold_late = (uint32_t)std::strtoul(e, nullptr, 10);
+        if (tune.tail >= 0) tail_threshold = tail_threshold_late = (uint32_t)tune.tail;
         // RT_PIXEL_BLOCKS=0: paths enter the queue along the pixel rows; =1: through 8 x 8 blocks of pixels, sample by
         // sample; unset: a wave holds several samples of a few neighbouring pixels (DBatch::blocked; same image always)
-        const char* pixel_blocks_env = std::getenv("RT_PIXEL_BLOCKS");
-        const bool pixel_blocks = !(pixel_blocks_env && pixel_blocks_env[0] == '0');
-        uint32_t runahead = 2;  // bounces enqueued beyond the last one whose live count the host has seen
-        if (const char* e = std::getenv("RT_RUNAHEAD")) runahead = (uint32_t)std::max(1l, std::min(64l, std::strtol(e, nullptr, 10)));
+        const bool pixel_blocks = tune.pixel_blocks != 0;
+        const uint32_t runahead = tune.runahead;  // bounces enqueued beyond the last one whose live count the host has seen
 
         std::vector<LaneRun> runs((size_t)K);
         for (int k = 0; k < K; k++) {
@@ -1123,8 +1152,8 @@ struct Engine : EngineBase {
                 b.bns = std::min(spb, s0 + ns - b.bs0);
                 b.n_paths = (uint32_t)(npix * b.bns);
                 b.n_tiles = tiles_for(b.n_paths);
-                b.B = rtd::DBatch{W, H, j0, (uint32_t)npix, b.bs0, 0u, seed, (uint32_t)(npix / W), pixel_blocks && W % 8 == 0 && (S.n_sweep == 0 || (pixel_blocks_env && pixel_blocks_env[0] == '2')) ? 1u : 0u};  // (tree walks only: a sweep has no lanes to keep in step; =2 forces it, A/B runs)
-                if (b.B.blocked && (pixel_blocks_env == nullptr || pixel_blocks_env[0] == '2')) b.B.blocked = 2u;  // pixels x samples per wave
+                b.B = rtd::DBatch{W, H, j0, (uint32_t)npix, b.bs0, 0u, seed, (uint32_t)(npix / W), pixel_blocks && W % 8 == 0 && (S.n_sweep == 0 || tune.pixel_blocks == 2) ? 1u : 0u};  // (tree walks only: a sweep has no lanes to keep in step; =2 forces it, A/B runs)
+                if (b.B.blocked && (tune.pixel_blocks < 0 || tune.pixel_blocks == 2)) b.B.blocked = 2u;  // pixels x samples per wave
                 b.depth = 0;
                 b.known_depth = 0;
                 b.known_alive = b.n_paths;

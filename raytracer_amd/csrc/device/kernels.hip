@@ -132,9 +132,6 @@ template <typename T> __device__ V3<T> random_in_unit_sphere(Rng<T>& rng) {  // 
         T py = rng.range((T)-1.0, (T)1.0);
         T pz = rng.range((T)-1.0, (T)1.0);
         V3<T> p = mk(px, py, pz);
-#if defined(RT_EXP) && (RT_EXP & 1)  // timing experiment only: wrong distribution
-        return p;
-#endif
         if (length_squared(p) <= (T)1.0) return p;
     }
 }
@@ -566,94 +563,23 @@ __device__ __forceinline__ void order2(float& ka, int32_t& ca, float& kb, int32_
     ka = k0; kb = k1; ca = c0; cb = c1;
 }
 
-#if defined(RT_EXP) && (RT_EXP & 256)
-__device__ unsigned long long g_live_hist[65];
-extern "C" void rt_exp_live(unsigned long long* out, int reset) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_live_hist), sizeof(g_live_hist));
-    if (reset) {
-        unsigned long long z[65] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_live_hist), z, sizeof(z));
-    }
-}
-// per wave of the tail launch: the clock (100 MHz) when it started, when the queue ran dry for it, when it ended
-__device__ unsigned long long g_live_ticks[65];  // clock ticks spent in iterations with that many live lanes
-extern "C" void rt_exp_live_ticks(unsigned long long* out) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_live_ticks), sizeof(g_live_ticks));
-    unsigned long long z[65] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_live_ticks), z, sizeof(z));
-}
-__device__ unsigned long long g_wave_clock[3][8192];
-extern "C" void rt_exp_wave_clock(unsigned long long* out) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_clock), sizeof(g_wave_clock));
-    static unsigned long long z[3][8192];
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_clock), z, sizeof(z));
-}
-#endif
-#if defined(RT_EXP) && (RT_EXP & 1024)  // measurement only: steps (nodes + leaves, both levels) per ray of k_extend, and per wave the longest
-__shared__ uint32_t g_lane_steps[256];
-__device__ unsigned long long g_step_hist[2048], g_wave_longest[2];  // [sum over waves of the longest walk, waves]
-// "stop a wave's walks after C steps": sum over waves of min(longest, C), and the histogram of what is left per ray
-__device__ unsigned long long g_cut_first[5], g_cut_left[5][2048];
-extern "C" void rt_exp_cut_hist(unsigned long long* first, unsigned long long* left) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(first, HIP_SYMBOL(g_cut_first), sizeof(g_cut_first));
-    (void)hipMemcpyFromSymbol(left, HIP_SYMBOL(g_cut_left), sizeof(g_cut_left));
-    static unsigned long long z[5][2048];
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_first), z, sizeof(g_cut_first));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_left), z, sizeof(g_cut_left));
-}
-// steps of every ray of the k_extend launch of one bounce, by its place in the launch (what would regrouping the
-// rays of a block or a tile by their kind buy?)
-__device__ unsigned short g_ray_steps[1 << 23];
-__device__ unsigned int g_ray_steps_depth = 0xffffffffu;
-extern "C" void rt_exp_ray_steps(unsigned short* out, unsigned int n, unsigned int depth_wanted) {
-    (void)hipDeviceSynchronize();
-    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_steps), (size_t)n * sizeof(unsigned short));
-    void* base = nullptr;
-    if (hipGetSymbolAddress(&base, HIP_SYMBOL(g_ray_steps)) == hipSuccess) (void)hipMemset(base, 0, sizeof(g_ray_steps));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ray_steps_depth), &depth_wanted, sizeof(depth_wanted));
-}
-__device__ unsigned long long g_mesh_live[65];  // wave-steps of the one-lane mesh walk by the number of lanes still in it
-#define RT_STEP_COUNT g_lane_steps[threadIdx.x]++
-#define RT_MESH_LIVE do { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_mesh_live[__popcll(m_)], 1ull); } while (0)
-extern "C" void rt_exp_mesh_live(unsigned long long* out) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mesh_live), sizeof(g_mesh_live));
-    unsigned long long z[65] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mesh_live), z, sizeof(z));
-}
-extern "C" void rt_exp_step_hist(unsigned long long* hist, unsigned long long* waves) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_step_hist), sizeof(g_step_hist));
-    (void)hipMemcpyFromSymbol(waves, HIP_SYMBOL(g_wave_longest), sizeof(g_wave_longest));
-    static unsigned long long z[2048];
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_hist), z, sizeof(g_step_hist));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_longest), z, sizeof(g_wave_longest));
-}
+// Measurement hooks (lane / wave step counts, live lanes of the tail launch, steps per ray): no-ops in the product
+// build; a library built with -DRT_EXP=<bits> takes their definitions from rt_measure.inc (scripts/exp_*.py).
+#ifdef RT_EXP
+#include "rt_measure.inc"
 #else
 #define RT_STEP_COUNT
 #define RT_MESH_LIVE
-#endif
-#if defined(RT_EXP) && (RT_EXP & 32)  // measurement only: lane / wave step counts of the four-wide walks (scripts/exp_steps.py)
-__device__ unsigned long long g_prof[8];
-#define RT_PROF_DECL uint32_t prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define RT_PROF(k) do { prof_[k]++; if ((__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) prof_[(k) + 1]++; } while (0)
-#define RT_PROF_FLUSH do { for (int k_ = 0; k_ < 8; k_++) if (prof_[k_]) atomicAdd(&g_prof[k_], (unsigned long long)prof_[k_]); } while (0)
-extern "C" void rt_exp_prof(unsigned long long* out, int reset) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof));
-    if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
-    }
-}
-#else
 #define RT_PROF_DECL
 #define RT_PROF(k)
 #define RT_PROF_FLUSH
+#define RT_EXTEND_STEPS_BEGIN
+#define RT_EXTEND_STEPS_END(depth, d, r, lane)
+#define RT_TAIL_WAVE_BEGIN
+#define RT_TAIL_QUEUE_DRY(exhausted)
+#define RT_TAIL_ITER_BEGIN(alive)
+#define RT_TAIL_ITER_END
+#define RT_TAIL_WAVE_END
 #endif
 
 // One step of a four-wide walk: the four child boxes of `n` against the ray, without branches - a
@@ -723,38 +649,6 @@ __device__ __forceinline__ int32_t node4_step(const Node4Regs& n, const RayF& f,
     return k0 < MISS ? c0 : RT_EMPTY;
 }
 
-#ifdef RT_BVH8
-// Experiment: one step of an EIGHT-wide mesh walk.  A node is two consecutive DNode4 records (tree_layout.hpp,
-// build_sah8): 8 boxes, the hit children sorted nearest first (a 19-exchange network), seven pushed at most.
-template <typename ST>
-__device__ __forceinline__ int32_t node8_step(const Node4Regs& n0, const Node4Regs& n1, const RayF& f, float tmin32, float bound32,
-                                              bool ordered, ST& st, int& sp) {
-    const float MISS = __int_as_float(0x7f800000);
-    float near[8], far[8];
-    node4_boxes(n0, f, tmin32, bound32, near, far);
-    node4_boxes(n1, f, tmin32, bound32, near + 4, far + 4);
-    int32_t c[8];
-    float k[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c[i] = i < 4 ? n0.child(i) : n1.child(i - 4);
-        k[i] = ((c[i] != RT_EMPTY) & (far[i] >= near[i])) ? (ordered ? near[i] : (float)i) : MISS;
-    }
-#define RT_CE(a, b) order2(k[a], c[a], k[b], c[b])
-    RT_CE(0, 1); RT_CE(2, 3); RT_CE(4, 5); RT_CE(6, 7);
-    RT_CE(0, 2); RT_CE(1, 3); RT_CE(4, 6); RT_CE(5, 7);
-    RT_CE(1, 2); RT_CE(5, 6); RT_CE(0, 4); RT_CE(3, 7);
-    RT_CE(1, 5); RT_CE(2, 6);
-    RT_CE(1, 4); RT_CE(3, 6);
-    RT_CE(2, 4); RT_CE(3, 5);
-    RT_CE(3, 4);
-#undef RT_CE
-#pragma unroll
-    for (int i = 7; i >= 1; i--)
-        if (k[i] < MISS) st.put(sp++, c[i]);
-    return k[0] < MISS ? c[0] : RT_EMPTY;
-}
-#endif
 
 // The same walk as blas_hit over the four-wide tree: one 128-byte fetch decides two levels of the
 // reference's tree, the children that are hit are visited nearest first (S.ordered) or in the
@@ -774,13 +668,8 @@ __device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T 
         RT_PROF(0);
         RT_STEP_COUNT;
         RT_MESH_LIVE;
-#ifdef RT_BVH8
-        const Node4Regs n = load_node4(S.nodes4, next), n_hi = load_node4(S.nodes4, next + 1);
-        next = node8_step(n, n_hi, f, tmin32, bound32, S.ordered != 0, st, sp);
-#else
         const Node4Regs n = load_node4(S.nodes4, next);
         next = node4_step(n, f, tmin32, bound32, S.ordered != 0, st, sp);
-#endif
         for (;;) {
             if (next == RT_EMPTY) {
                 if (sp == sp0) {
@@ -796,18 +685,7 @@ __device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T 
             const int tri = -1 - next;  // leaf: the exact test, against the current bound (t == bound passes)
             T t;
             const DTriangle<T> tr = S.triangles[tri];
-#if defined(RT_EXP) && (RT_EXP & 512)  // timing experiment only: the triangle test in f32 arithmetic (what the f64 arithmetic of the leaves costs)
-            V3<float> sf;
-            bool hit_f = line_plane_collision(V3<float>{(float)r.o.x, (float)r.o.y, (float)r.o.z}, V3<float>{(float)r.d.x, (float)r.d.y, (float)r.d.z},
-                                              V3<float>{(float)tr.point[0], (float)tr.point[1], (float)tr.point[2]},
-                                              V3<float>{(float)tr.vec1[0], (float)tr.vec1[1], (float)tr.vec1[2]},
-                                              V3<float>{(float)tr.vec2[0], (float)tr.vec2[1], (float)tr.vec2[2]}, &sf);
-            hit_f = hit_f && !(sf.x < (float)min_dist || sf.x > (float)max_dist) && !(sf.y < 0.0f || sf.z < 0.0f || sf.y + sf.z > 1.0f);
-            t = (T)sf.x;
-            if (hit_f) {
-#else
             if (triangle_hit(tr, r, min_dist, max_dist, &t)) {
-#endif
                 if (!found || t < max_dist || tr.dfs_rank > best_rank) {
                     max_dist = t;
                     bound32 = round_up(t - (T)shift);
@@ -1008,11 +886,7 @@ __device__ __noinline__ T medium_log_draw(PathRef path, uint32_t rng_key, uint32
     return log(rng.next());
 }
 
-#ifdef RT_MEDIUM_NOINLINE
-#define RT_MEDIUM_ATTR __noinline__
-#else
-#define RT_MEDIUM_ATTR
-#endif
+#define RT_MEDIUM_ATTR  // (out of line it cost 70 %: the call's own saves and the lost scalarisation)
 template <typename T, bool UNIFORM, int FEAT, typename ST>
 __device__ RT_MEDIUM_ATTR bool medium_hit(const DScene<T>& S, const DObject ob, const Ray<T>& world_ray, T min_dist, T max_dist, ST st,
                                           int sp, float shift, PathRef path, uint32_t depth, T* t_out, int* prim_out);
@@ -1201,12 +1075,6 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
             for (int k = 0; k < S.n_sweep; k++) {
                 const int oi = rec<true>(&S.sweep[k]);
                 const DObject ob = rec<true>(&S.objects[oi]);
-#if defined(RT_EXP) && (RT_EXP & 4)  // timing experiment only: no transformed objects
-                if (ob.xform >= 0) continue;
-#endif
-#if defined(RT_EXP) && (RT_EXP & 8)  // timing experiment only: transformed objects only
-                if (ob.xform < 0 && k > 0) continue;
-#endif
                 T th = 0;
                 int prim = -1;
                 bool hit;
@@ -1693,29 +1561,10 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
         T max_dist = tmax_arr ? tmax_arr[i] : Lim<T>::inf();
         T t;
         Winner w;
-#if defined(RT_EXP) && (RT_EXP & 1024)
-        g_lane_steps[threadIdx.x] = 0;
+        RT_EXTEND_STEPS_BEGIN;
         const bool got = closest_hit<T, MODE>(S, r, min_dist, max_dist, st, path, depth, &t, &w);
-        {
-            const uint32_t steps = g_lane_steps[threadIdx.x];
-            if (depth == g_ray_steps_depth && d < (1u << 23))  // steps (12 bits) | octant of the direction << 12
-                g_ray_steps[d] = (unsigned short)(min(steps, 4095u) | ((r.d.x < (T)0.0 ? 1u : 0u) | (r.d.y < (T)0.0 ? 2u : 0u) | (r.d.z < (T)0.0 ? 4u : 0u)) << 12);
-            atomicAdd(&g_step_hist[min(steps, 2047u)], 1ull);
-            uint32_t longest = steps;
-            for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
-            const uint32_t cuts[5] = {8, 16, 24, 32, 48};
-            for (int c = 0; c < 5; c++)
-                if (steps > cuts[c]) atomicAdd(&g_cut_left[c][min(steps - cuts[c], 2047u)], 1ull);
-            if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) {
-                atomicAdd(&g_wave_longest[0], (unsigned long long)longest);
-                atomicAdd(&g_wave_longest[1], 1ull);
-                for (int c = 0; c < 5; c++) atomicAdd(&g_cut_first[c], (unsigned long long)min(longest, cuts[c]));
-            }
-        }
+        RT_EXTEND_STEPS_END(depth, d, r, lane);
         if (got) {
-#else
-        if (closest_hit<T, MODE>(S, r, min_dist, max_dist, st, path, depth, &t, &w)) {
-#endif
             Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(S, r, t, w, S.needs_uv != 0 || h.owner != nullptr);
             h.t()[i] = t;
             h.nx()[i] = sf.normal.x; h.ny()[i] = sf.normal.y; h.nz()[i] = sf.normal.z;
@@ -2068,20 +1917,12 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
         // (the dearest part of the shading) together instead of once per material.  (SHARED_DRAW = false:
         // drawn inside each case - 1 % faster where nearly every hit is Lambertian, the lean sweep's k_bounce.)
         V3<T> in_sphere = mk((T)0.0, (T)0.0, (T)0.0);
-#if defined(RT_EXP) && (RT_EXP & 2)  // timing experiment only: no random numbers for Lambertian
-        if (SHARED_DRAW && (m.type == RT_MAT_METAL || m.type == RT_MAT_ISOTROPIC)) in_sphere = random_in_unit_sphere(rng);
-#else
         if (SHARED_DRAW && (m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_METAL || m.type == RT_MAT_ISOTROPIC))
             in_sphere = random_in_unit_sphere(rng);
-#endif
         switch (m.type) {
             case RT_MAT_LAMBERTIAN: {  // src/materials.rs:27-42
-#if defined(RT_EXP) && (RT_EXP & 2)
-                dir = n + mk((T)0.1, (T)0.2, (T)0.3) * ray.d.x;
-#else
                 if (!SHARED_DRAW) in_sphere = random_in_unit_sphere(rng);
                 dir = n + unit_vector(in_sphere);
-#endif
                 if (near_zero(dir)) dir = n;
                 attenuation = texture_value(S, m, u, v);
                 scattered = true;
@@ -2128,14 +1969,6 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
             thr = coeff(thr, attenuation);
         }
     }
-#if defined(RT_EXP) && (RT_EXP & 64)  // traffic experiment only: the sample is not written
-    if (contributes && add.x == (T)-1.0) sample_rgb[0] = add.y + add.z;
-#elif defined(RT_EXP) && (RT_EXP & 128)  // traffic experiment only: store instead of read-modify-write
-    if (contributes) {
-        T* dst = sample_rgb + (uint64_t)pid * 3;
-        dst[0] = add.x; dst[1] = add.y; dst[2] = add.z;
-    }
-#else
     if (contributes) {
         // The sample buffer starts at zero.  Where a path can only add once (DScene::emit_once) the sum is the
         // addend itself: a plain store, no read of the line (cornell: 11 % of k_bounce's HBM-side reads).
@@ -2146,7 +1979,6 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
             dst[0] += add.x; dst[1] += add.y; dst[2] += add.z;
         }
     }
-#endif
     return alive;
 }
 
@@ -2211,13 +2043,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DScene<T> S, DB
                 }
                 n = mk(h.nx()[i], h.ny()[i], h.nz()[i]);
             }
-#if defined(RT_EXP) && (RT_EXP & 2048)  // timing experiment only: what k_shade costs with no shading in it (its memory floor)
-            alive = mf != RT_MISS && depth + 1 < max_bounces;
-            nr.o = ray.at(t); nr.d = n; nr.time = ray.time;
-            if (mf == RT_MISS) sample_rgb[(uint64_t)pid * 3] = thr.x;
-#else
             alive = shade_path(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
-#endif
         }
         compact_store(alive, tile, nr, thr, pid, qout, tile_counts_out);
     }
@@ -2264,14 +2090,9 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
             hit = closest_hit<T, MODE>(W, ray, (T)0.001, Lim<T>::inf(), st, path, depth, &t, &w);  // src/hitting.rs:20-21
         }
         if (hit) {
-#if defined(RT_EXP) && (RT_EXP & 16)  // timing experiment only: no surface reconstruction
-            n = mk((T)0.0, (T)1.0, (T)0.0);
-            mf = (uint32_t)W.rects[w.prim].material | 0x80000000u;
-#else
             const Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(W, ray, t, w, S.needs_uv != 0);
             n = sf.normal; u = sf.u; v = sf.v;
             mf = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
-#endif
         }
         return shade_path<T, MODE != WALK_SWEEP_LEAN>(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
     };
@@ -2301,11 +2122,7 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
         // lane whose path has ended takes the next one of the share, so the waves stay full until the queue is
         // empty, and the launch ends as long after that as its longest path.
         uint32_t extra_queries = 0, deepest = depth0, taken = 0;
-#ifdef RT_NO_COOP  // (A/B builds: what the group code costs the full waves)
-        constexpr bool COOP_MODE = false;
-#else
         constexpr bool COOP_MODE = walks_node4(MODE);  // (meshes: the mesh walk is shared out; without: the world walk)
-#endif
         const uint32_t CHUNK = max(64u, min(1024u, (total / (gridDim.x * (BLOCK / 64) * 8u)) & ~63u));
         uint32_t chunk_lo = 0, chunk_hi = 0;  // (wave-uniform) what is left of the wave's share
         bool exhausted = false;               // (wave-uniform)
@@ -2315,11 +2132,7 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
         uint32_t pid = 0, depth = depth0;
         ray.o = ray.d = thr = mk((T)0.0, (T)0.0, (T)0.0);
         ray.time = (T)0.0;
-#if defined(RT_EXP) && (RT_EXP & 256)
-        const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
-        bool noted = false;
-        if (lane == 0 && wave_id < 8192) g_wave_clock[0][wave_id] = wall_clock64();
-#endif
+        RT_TAIL_WAVE_BEGIN;
         for (;;) {
             while (!exhausted) {
                 const uint64_t idle = __ballot(!alive);
@@ -2349,18 +2162,9 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
                 }
                 chunk_lo += min((uint32_t)__popcll(idle), avail);
             }
-#if defined(RT_EXP) && (RT_EXP & 256)
-            if (exhausted && !noted) {
-                noted = true;
-                if (lane == 0 && wave_id < 8192) g_wave_clock[1][wave_id] = wall_clock64();
-            }
-#endif
+            RT_TAIL_QUEUE_DRY(exhausted);
             if (__ballot(alive) == 0) break;
-#if defined(RT_EXP) && (RT_EXP & 256)  // measurement only: live lanes per wave and iteration of the tail launch (scripts/exp_tail_live.py)
-            const int live_now = __popcll(__ballot(alive));
-            const unsigned long long tick0 = wall_clock64();
-            if (lane == 0) atomicAdd(&g_live_hist[live_now], 1ull);
-#endif
+            RT_TAIL_ITER_BEGIN(alive);
             // A wave with a few live lanes left (the end of the launch is waves of ONE path each, walking the mesh at
             // one lane's pace): each live path's query is answered by a group of 64 / 32 / 16 / 8 lanes.
             Answer ans;
@@ -2405,13 +2209,9 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
                 ray = nr;  // the scattered ray is the next bounce's query
                 depth++;
             }
-#if defined(RT_EXP) && (RT_EXP & 256)
-            if (lane == 0) atomicAdd(&g_live_ticks[live_now], wall_clock64() - tick0);
-#endif
+            RT_TAIL_ITER_END;
         }
-#if defined(RT_EXP) && (RT_EXP & 256)
-        if (lane == 0 && wave_id < 8192) g_wave_clock[2][wave_id] = wall_clock64();
-#endif
+        RT_TAIL_WAVE_END;
         // rays and depth statistics of the bounces that were not launches
         for (int off = 32; off > 0; off >>= 1) {
             extra_queries += __shfl_xor(extra_queries, off);

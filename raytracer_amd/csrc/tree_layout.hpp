@@ -437,65 +437,6 @@ inline bool build_sah4(const rt_scene_desc& d, int32_t root, float pad, std::vec
     return true;
 }
 
-// ---- Eight-wide mesh trees (experiment, SURVEY 8f rank 3: "8-wide quantised nodes"; RT_BVH8=1 + a library built
-// with -DRT_BVH8).  A node is a PAIR of consecutive WideNode4 records (slots 0-3 and 4-7, each quantised on its own
-// grid by quantize_nodes4, 2 x 64 B); child references name the first record of a pair.  Same SAH splits, opened until
-// a node has eight children.  Measured against the four-wide trees in DESIGN.md section 3.
-inline int32_t sah8_node(std::vector<SahLeaf>& L, size_t lo, size_t hi, std::vector<rtd::WideNode4>& out, int* need) {
-    std::vector<SahPart> parts{make_part(L, lo, hi)};
-    while (parts.size() < 8) {
-        int pick = -1;
-        for (size_t k = 0; k < parts.size(); k++)
-            if (parts[k].hi - parts[k].lo > 1 && (pick < 0 || parts[k].area > parts[(size_t)pick].area)) pick = (int)k;
-        if (pick < 0) break;
-        const SahPart p = parts[(size_t)pick];
-        const size_t mid = sah_split(L, p.lo, p.hi);
-        parts[(size_t)pick] = make_part(L, p.lo, mid);
-        parts.insert(parts.begin() + pick + 1, make_part(L, mid, p.hi));
-    }
-    std::stable_sort(parts.begin(), parts.end(), [](const SahPart& a, const SahPart& b) { return a.area > b.area; });
-    const int32_t me = (int32_t)out.size();
-    out.emplace_back();
-    out.emplace_back();
-    rtd::WideNode4 n[2];
-    std::memset(n, 0, sizeof(n));
-    int deepest = 0;
-    for (int k = 0; k < 8; k++) {
-        rtd::WideNode4& half = n[k / 4];
-        half.child[k % 4] = rtd::RT_EMPTY;
-        if ((size_t)k >= parts.size()) continue;
-        const SahPart& p = parts[(size_t)k];
-        half.set_box(k % 4, p.blo, p.bhi);
-        int below = 0;
-        half.child[k % 4] = p.hi - p.lo == 1 ? L[p.lo].ref : sah8_node(L, p.lo, p.hi, out, &below);
-        deepest = std::max(deepest, below);
-    }
-    out[(size_t)me] = n[0];
-    out[(size_t)me + 1] = n[1];
-    *need = (int)parts.size() - 1 + deepest;
-    return me;
-}
-inline bool build_sah8(const rt_scene_desc& d, int32_t root, float pad, std::vector<rtd::WideNode4>& out, int32_t* root_out, int* need) {
-    std::vector<SahLeaf> L;
-    if (!collect_leaves(d, root, pad, L)) return false;
-    const int32_t me = (int32_t)out.size();
-    out.emplace_back();
-    out.emplace_back();
-    rtd::WideNode4 n[2];
-    std::memset(n, 0, sizeof(n));
-    for (int k = 0; k < 8; k++) n[k / 4].child[k % 4] = rtd::RT_EMPTY;
-    *need = 0;
-    if (!L.empty()) {
-        const SahPart all = make_part(L, 0, L.size());
-        n[0].set_box(0, all.blo, all.bhi);
-        n[0].child[0] = L.size() == 1 ? L[0].ref : sah8_node(L, 0, L.size(), out, need);
-    }
-    out[(size_t)me] = n[0];
-    out[(size_t)me + 1] = n[1];
-    *root_out = me;
-    return true;
-}
-
 // DNode2 super-root for the reference BVH rooted at `root`: child 0 = that root, child 1 empty.
 inline int32_t build_nodes2(const rt_scene_desc& d, int32_t root, float pad, std::vector<rtd::DNode2>& out, LeafRanks& ranks) {
     int32_t me = (int32_t)out.size();

@@ -293,8 +293,8 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
 # ---------------------------------------------------------------- every traversal layout gives the same answer
 # The library picks a traversal per scene (sweep of a few objects, own-box nodes in LDS, DNode2 tree
 # walk nearer-child-first, fused extend+shade).  They are different programs for the same function:
-# the images must agree bit for bit, and so must the hits.  The environment switches are read when a
-# scene is uploaded (RT_SWEEP_MAX, RT_ORDERED) / when a render starts (RT_FUSE).
+# the images must agree bit for bit, and so must the hits.  The environment switches are read ONCE, when a
+# context is created (capi.cpp, struct Tuning): every case makes its own.
 @pytest.mark.parametrize(
     "name, env",
     [
@@ -378,7 +378,10 @@ def test_the_order_of_the_queue_does_not_change_the_image(rt, gpu_scenes, name, 
             monkeypatch.delenv("RT_PIXEL_BLOCKS", raising=False)
         else:
             monkeypatch.setenv("RT_PIXEL_BLOCKS", order)
-        results.append(gpu_scenes(name)[1].render_rows(width, H, j0, j1, spp, 12, seed=31))
+        r = rt.Renderer(device=0, precision=0)   # (the switches are read when a context is created)
+        r.upload(sc)
+        results.append(r.render_rows(width, H, j0, j1, spp, 12, seed=31))
+        r.close()
     for rgb8, sums, st in results[1:]:
         assert st.rays == results[0][2].rays
         assert np.array_equal(sums, results[0][1])
