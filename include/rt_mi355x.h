@@ -321,6 +321,10 @@ typedef void (*rt_band_callback)(void* user, uint32_t b0, uint32_t b1);
 int rt_multi_render_rows_cb(rt_multi* m, uint32_t width, uint32_t height, uint32_t j0, uint32_t j1, uint32_t spp,
                             uint32_t max_bounces, uint64_t seed, uint32_t band_rows, uint8_t* rgb8, double* sum_rgb,
                             rt_stats* stats, rt_band_callback on_band, void* user);
+/* Loads RCCL as rt_multi_create would (a copy the process already holds; else the file RT_RCCL_LIB names; else the one next to
+ * the HIP runtime this process runs on; else the loader's search path) and returns the path of the file in use, or NULL
+ * (rt_multi_last_error(NULL) says why).  Needs no GPU.  For hosts that must keep ONE ROCm stack in the process. */
+const char* rt_multi_rccl_library(void);
 /* The partition rule: part `part` of `parts` gets `count` consecutive items from `begin`; the ranges cover
  * [first, first + total) exactly once and the first total % parts parts take one extra item. */
 void rt_split_samples(uint32_t total, uint32_t parts, uint32_t part, uint32_t first, uint32_t* begin, uint32_t* count);

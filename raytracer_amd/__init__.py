@@ -99,6 +99,7 @@ EXPORTS = [
     ("rt_multi_destroy", None, [_vp]),
     ("rt_multi_device_count", C.c_int, [_vp]),
     ("rt_multi_last_error", C.c_char_p, [_vp]),
+    ("rt_multi_rccl_library", C.c_char_p, []),
     ("rt_multi_upload_scene", C.c_int, [_vp, _vp]),
     ("rt_multi_set_launch_timing", C.c_int, [_vp, C.c_int]),
     ("rt_multi_render_rows", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _u32, _vp, _vp, C.POINTER(RtStats)]),
@@ -137,10 +138,7 @@ def _share_torch_hip_runtime() -> None:
     path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
     if os.path.exists(path):
         C.CDLL(path, mode=C.RTLD_GLOBAL)
-    # the same for RCCL, which rt_multi_create loads on demand (dlopen): name torch's copy, do not load it here
-    rccl = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
-    if os.path.exists(rccl):
-        os.environ.setdefault("RT_RCCL_LIB", rccl)
+    # (RCCL, which rt_multi_create loads on demand, is then taken from next to that runtime by the library itself: multi.cpp)
 
 
 def load_library() -> C.CDLL:

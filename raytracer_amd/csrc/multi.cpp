@@ -9,12 +9,13 @@
 // With fewer samples than GPUs the rows of a band are split instead and nothing is reduced.
 //
 // RCCL is loaded with dlopen the first time a context with more than one distinct device is made (a process that
-// has torch loaded already holds a copy; linking another one in would clash).  RT_REDUCE=p2p in the environment
+// has torch loaded already holds a copy; linking another one in would clash - Rccl::load says which copy and why).  RT_REDUCE=p2p in the environment
 // (and any device list that names a GPU twice, which RCCL does not allow) takes the copy-and-add path instead:
 // every peer's buffer is copied to device 0 over its own xGMI link (hipMemcpyPeerAsync) and added there.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -51,26 +52,49 @@ struct Rccl {
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
+    std::string path;  // the file in use
     bool load() {
         if (handle) return true;
-        // A copy the process holds already (torch bundles its own) is the one to use: two RCCLs in one process end
-        // in a double free at exit.  RT_RCCL_LIB names the file to load otherwise (the Python bindings point it at
-        // torch's copy, which a later `import torch` would load anyway).
+        // ONE copy of the ROCm stack per process.  PyTorch wheels bundle their own (torch/lib/libamdhip64.so, librccl.so, ...)
+        // and ask for it by unversioned file names that match no SONAME of the system copies (libamdhip64.so.7,
+        // librccl.so.1): a process that has /opt/rocm's RCCL - and with it /opt/rocm's HIP runtime, rocm_smi, ... - and then
+        // imports torch holds every library twice and aborts at exit ("free(): invalid pointer"; reproduced without a GPU,
+        // tests/test_host_io.py).  So RCCL is taken, in this order, from: a copy the process holds already (RTLD_NOLOAD);
+        // the file RT_RCCL_LIB names; the directory of the HIP runtime THIS process runs on (torch's if torch's runtime is the
+        // one loaded - the Python bindings load it first -, /opt/rocm's for a plain FFI host); the loader's search path.
+        // And always RTLD_LOCAL: with torch's own librccl.so opened RTLD_GLOBAL before `import torch`, the process still
+        // ended in "double free or corruption" at exit although it held one copy of every library - RCCL's global symbols
+        // interposed on definitions of the torch libraries loaded after it.  Its entry points are looked up with dlsym.
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
-            handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+            handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);  // (never RTLD_GLOBAL: that would promote the copy)
             if (handle) break;
         }
         // (dlerror() hands its text out once and clears it: read once, right after the dlopen that failed)
         std::string last_failure;
         auto open = [&](const char* file) {
-            handle = dlopen(file, RTLD_NOW | RTLD_GLOBAL);
+            handle = dlopen(file, RTLD_NOW | RTLD_LOCAL);  // (local: its symbols must not interpose on libraries loaded later, see below)
             if (!handle) {
                 const char* e = dlerror();
                 last_failure = e ? e : std::string(file) + " not found";
             }
         };
-        if (const char* path = std::getenv("RT_RCCL_LIB"); !handle && path && path[0]) open(path);
+        if (const char* env = std::getenv("RT_RCCL_LIB"); !handle && env && env[0]) open(env);
+        if (!handle) {
+            Dl_info hip;
+            void* sym = dlsym(RTLD_DEFAULT, "hipGetDeviceCount");
+            if (sym && dladdr(sym, &hip) && hip.dli_fname) {
+                std::string dir(hip.dli_fname);
+                const size_t slash = dir.rfind('/');
+                if (slash != std::string::npos) {
+                    dir.resize(slash + 1);
+                    for (const char* n : {"librccl.so.1", "librccl.so"}) {
+                        if (handle) break;
+                        if (access((dir + n).c_str(), R_OK) == 0) open((dir + n).c_str());
+                    }
+                }
+            }
+        }
         for (const char* n : names) {
             if (handle) break;
             open(n);
@@ -88,6 +112,8 @@ struct Rccl {
             handle = nullptr;
             return false;
         }
+        Dl_info where;
+        path = dladdr((void*)Reduce, &where) && where.dli_fname ? where.dli_fname : "";
         return true;
     }
 };
@@ -216,6 +242,15 @@ void rt_split_samples(uint32_t total, uint32_t parts, uint32_t part, uint32_t fi
 }
 
 const char* rt_multi_last_error(const rt_multi* m) { return m ? m->error.c_str() : g_multi_error.c_str(); }
+
+const char* rt_multi_rccl_library(void) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (!g_rccl.load()) {
+        g_multi_error = g_rccl.why;
+        return nullptr;
+    }
+    return g_rccl.path.c_str();
+}
 
 void rt_multi_destroy(rt_multi* m) {
     if (!m) return;

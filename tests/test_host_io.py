@@ -397,3 +397,79 @@ def test_multi_create_without_a_gpu_is_an_error_code():
     assert e.value.code == -2
     r = subprocess.run([CLI, "--help"], capture_output=True)
     assert b"--gpus <n>" in r.stdout and b"--devices <a,b,..>" in r.stdout
+
+
+# ---- one ROCm stack per process, whatever the loading order.  PyTorch wheels bundle
+# their own ROCm libraries and ask for them by unversioned file names that match no SONAME of /opt/rocm's copies, so a process
+# that loads /opt/rocm's RCCL and then imports torch holds everything twice and aborts at exit - reproduced here without a GPU
+# (`forbidden`), and what the library and its bindings do so that it cannot happen through them.
+_LOADER_SCRIPT = r"""
+import ctypes, os, sys
+order = sys.argv[1]
+lib_path = sys.argv[2]
+def mapped(key):
+    return sorted({l.split()[-1] for l in open('/proc/self/maps') if key in l and '.so' in l})
+if order == 'ffi_host_rccl_first':          # a host that links the system RCCL before it loads the library; no torch
+    ctypes.CDLL('/opt/rocm/lib/librccl.so.1', mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(lib_path)
+elif order == 'bindings_then_torch':
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(lib_path))))
+    import raytracer_amd
+    lib = raytracer_amd.load_library()
+elif order == 'torch_then_bindings':
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(lib_path))))
+    import raytracer_amd
+    lib = raytracer_amd.load_library()
+elif order == 'forbidden':                  # the system stack, then torch, behind the library's back
+    ctypes.CDLL('/opt/rocm/lib/librccl.so.1', mode=ctypes.RTLD_GLOBAL)
+    import torch
+    print('LIBS', len(mapped('librccl')), len(mapped('libamdhip64')))
+    sys.exit(0)
+lib.rt_multi_rccl_library.restype = ctypes.c_char_p
+path = lib.rt_multi_rccl_library()
+print('RCCL', path.decode() if path else None)
+if order == 'bindings_then_torch':
+    import torch
+print('LIBS', len(mapped('librccl')), len(mapped('libamdhip64')), len(mapped('libhsa-runtime64')))
+"""
+
+
+@pytest.mark.parametrize("order", ["ffi_host_rccl_first", "bindings_then_torch", "torch_then_bindings"])
+def test_one_rocm_stack_per_process_whatever_the_loading_order(order, tmp_path):
+    import subprocess
+    import sys
+
+    import raytracer_amd
+
+    if not os.path.exists("/opt/rocm/lib/librccl.so.1"):
+        pytest.skip("no system RCCL")
+    script = tmp_path / "order.py"
+    script.write_text(_LOADER_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RT_RCCL_LIB", "RT_REDUCE")}
+    p = subprocess.run([sys.executable, str(script), order, raytracer_amd.LIB_PATH], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, (p.returncode, p.stderr[-500:])            # in particular: no abort at exit
+    assert "free()" not in p.stderr and "double free" not in p.stderr
+    out = dict(line.split(" ", 1) for line in p.stdout.splitlines() if " " in line)
+    assert out["LIBS"].split() == ["1", "1", "1"], p.stdout               # one RCCL, one HIP runtime, one HSA runtime
+    if order == "ffi_host_rccl_first":
+        assert out["RCCL"].startswith("/opt/rocm")                        # the copy the host holds already
+    else:
+        assert "/torch/lib/librccl.so" in out["RCCL"]                      # the one next to the HIP runtime the process runs on
+
+
+def test_the_order_the_library_avoids_does_abort(tmp_path):
+    # the cause, kept visible: /opt/rocm's RCCL first, then `import torch` -> two of everything and an abort at exit
+    import subprocess
+    import sys
+
+    import raytracer_amd
+
+    if not os.path.exists("/opt/rocm/lib/librccl.so.1"):
+        pytest.skip("no system RCCL")
+    script = tmp_path / "order.py"
+    script.write_text(_LOADER_SCRIPT)
+    p = subprocess.run([sys.executable, str(script), "forbidden", raytracer_amd.LIB_PATH], capture_output=True, text=True, timeout=300)
+    if p.returncode == 0 and "LIBS 1 1" in p.stdout:
+        pytest.skip("this torch build shares the system ROCm libraries")
+    assert "LIBS 2 2" in p.stdout    # two RCCLs, two HIP runtimes in one process
