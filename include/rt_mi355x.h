@@ -28,7 +28,8 @@ typedef enum rt_status {
     RT_ERR_NO_SCENE = -3,  /* render / trace before rt_upload_scene */
     RT_ERR_SCENE = -4,     /* scene file cannot be read / parsed / constructed */
     RT_ERR_UNSUPPORTED = -5,
-    RT_ERR_IO = -6
+    RT_ERR_IO = -6,
+    RT_ERR_BUSY = -7       /* rt_render_accum_device_noalloc: another call holds this GPU's static work area */
 } rt_status;
 
 /* ------------------------------------------------------------------ flattened scene
@@ -267,14 +268,16 @@ int rt_render_accum_device(rt_context* ctx, uint32_t width, uint32_t height, uin
                            uint32_t s0, uint32_t n_samples, uint32_t max_bounces, uint64_t seed,
                            double* accum_dev, rt_stats* stats /* may be NULL */);
 
-/* The same call for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  It calls no hipMalloc / hipFree (nor
- * any other allocating routine): the ray queues, hit records and per-path samples live in a static device array of
- * the library (32 MiB per GPU, held from the moment the library is loaded on that GPU until the process ends), sized
- * for RT_NOALLOC_MAX_PATHS = 131072 paths in flight.  Limit: width * (j1 - j0) <= 131072 pixels per call (RT_ERR_INVALID
- * with a message otherwise); the samples are traced in batches of floor(131072 / pixels) and added in sample order,
- * so accum is bit-identical to rt_render_accum_device's.  Every call on a GPU - from any context - uses that GPU's one
- * array: calls that overlap on one GPU race; make them one after the other.  No statistics, no launch timing. */
+/* The same call for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc).  It
+ * has no counterpart in the reference.  It calls no hipMalloc / hipFree (nor any other allocating routine): the ray queues,
+ * hit records and per-path samples live in a static device array of the library (32 MiB per GPU, held from the moment the
+ * library is loaded on that GPU until the process ends), sized for RT_NOALLOC_MAX_PATHS = 131072 paths in flight.  Like
+ * every render call it follows the live counts from the host and synchronises the context's stream before it returns (so it
+ * is not a call to make while a stream is being captured into a graph).  Limit: width * (j1 - j0) <= 131072 pixels per call
+ * (RT_ERR_INVALID with a message otherwise); the samples are traced in batches of floor(131072 / pixels) and added in sample
+ * order, so accum is bit-identical to rt_render_accum_device's.  Every call on a GPU - from any context - uses that GPU's one
+ * array: a call that arrives while another holds it returns RT_ERR_BUSY at once (nothing is traced); make them one after
+ * the other.  No statistics, no launch timing. */
 #define RT_NOALLOC_MAX_PATHS 131072u
 int rt_render_accum_device_noalloc(rt_context* ctx, uint32_t width, uint32_t height, uint32_t j0, uint32_t j1,
                                    uint32_t s0, uint32_t n_samples, uint32_t max_bounces, uint64_t seed,
@@ -351,8 +354,9 @@ int rt_part_file_finish(rt_part_file* part, int remove);
 int rt_part_file_read(const char* name, uint32_t image_height, uint32_t image_width, int recover_corrupt,
                       uint8_t* rows, uint8_t* present);
 
-/* img.save(output_file) (src/main.rs:161-162): rgb8 is width*height*3 bytes, top row first; the
- * encoder follows the extension (.png, .jpg/.jpeg - baseline JFIF, quality 75 -, .ppm/.pnm, .bmp; anything else is RT_ERR_IO). */
+/* img.save(output_file) (src/main.rs:161-162): rgb8 is width*height*3 bytes, top row first; the encoder follows the
+ * extension: .png, .jpg / .jpeg (baseline JFIF, quality 75), .ppm / .pnm, .pam, .bmp, .tga, .tif / .tiff (one uncompressed
+ * strip), .ff (farbfeld); anything else is RT_ERR_IO ("not supported"). */
 int rt_save_image(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb8);
 
 /* TimedProgressBar (src/progress.rs:12-115) drawing on a duplicate of file descriptor fd. */

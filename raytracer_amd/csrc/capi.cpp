@@ -6,6 +6,7 @@
 // and fails with RT_ERR_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -305,7 +306,12 @@ Work<T> carve_work(unsigned char* base, size_t bytes, size_t paths) {
 // One lane: a stream, its work buffers and the pinned words through which the kernels tell the host how
 // many paths are alive (k_scan_tiles stores the count of every bounce there; the host never waits for the
 // stream to learn it).
-constexpr uint32_t PEEK_SLOTS = 256;  // ring of per-bounce live counts, indexed by depth % PEEK_SLOTS
+// Two rings of per-bounce live counts per lane, indexed by depth % PEEK_SLOTS; a lane's batches alternate between them.
+// A batch can be finished by the host while its last scans are still queued on the GPU (the tail launch needs no
+// count): their late stores must not land in the ring the lane's NEXT batch is reading, which has re-marked its slots
+// unknown meanwhile - a stale count there would be taken for the new batch's own.  By the time the batch after next
+// reuses a ring, the host has read a count of the batch between (stored by a scan that ran after all of this one's).
+constexpr uint32_t PEEK_SLOTS = 128;
 constexpr uint32_t PEEK_UNKNOWN = 0xffffffffu;
 template <typename T>
 struct Lane {
@@ -325,7 +331,7 @@ struct Lane {
             HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
             own_stream = true;
         }
-        HIP_CHECK(hipHostMalloc((void**)&peek, PEEK_SLOTS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_CHECK(hipHostMalloc((void**)&peek, 2 * PEEK_SLOTS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
         HIP_CHECK(hipHostMalloc((void**)&readback, 4 * sizeof(unsigned long long), hipHostMallocDefault));
         HIP_CHECK(hipEventCreateWithFlags(&ev_acc, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
@@ -353,7 +359,9 @@ struct Lane {
         HIP_CHECK(hipHostGetDevicePointer(&d, peek, 0));
         return (uint32_t*)d;
     }
-    uint32_t peek_value(uint32_t depth) const { return __atomic_load_n(&peek[depth % PEEK_SLOTS], __ATOMIC_ACQUIRE); }
+    uint32_t ring = 0;  // which of the two rings the lane's current batch uses
+    uint32_t peek_slot(uint32_t depth) const { return ring * PEEK_SLOTS + depth % PEEK_SLOTS; }
+    uint32_t peek_value(uint32_t depth) const { return __atomic_load_n(&peek[peek_slot(depth)], __ATOMIC_ACQUIRE); }
     hipEvent_t event(size_t k) {
         while (events.size() <= k) {
             hipEvent_t e;
@@ -1158,7 +1166,8 @@ struct Engine : EngineBase {
                 b.known_depth = 0;
                 b.known_alive = b.n_paths;
                 b.active = true;
-                for (uint32_t k = 0; k < PEEK_SLOTS; k++) L.peek[k] = PEEK_UNKNOWN;
+                L.ring ^= 1u;
+                for (uint32_t k = 0; k < PEEK_SLOTS; k++) L.peek[L.ring * PEEK_SLOTS + k] = PEEK_UNKNOWN;
                 __atomic_thread_fence(__ATOMIC_SEQ_CST);
                 HIP_CHECK(hipMemsetAsync(w.sample_rgb, 0, (size_t)b.n_paths * 3 * sizeof(T), st));
                 rtd::Launch<T>::raygen(S, b.B, queue(w, 0), b.n_paths, w.tile_counts[0], st);
@@ -1220,10 +1229,10 @@ struct Engine : EngineBase {
             }
             // offsets of the queue just written, clear the counts of the other one, rays += survivors, and the
             // live count to the host
-            L.peek[(depth + 1) % PEEK_SLOTS] = PEEK_UNKNOWN;
+            L.peek[L.peek_slot(depth + 1)] = PEEK_UNKNOWN;
             __atomic_thread_fence(__ATOMIC_SEQ_CST);
             rtd::launch_scan_tiles(w.tile_counts[out], b.n_tiles, w.tile_offsets, w.tile_counts[in], w.counts, w.ray_total,
-                                   L.peek_dev() + (depth + 1) % PEEK_SLOTS, st);
+                                   L.peek_dev() + L.peek_slot(depth + 1), st);
             if (timing) HIP_CHECK(hipEventRecord(L.event(R.ev + 2), st));
             if (timing) R.ev += 3;
             R.deepest = std::max(R.deepest, depth + 1);
@@ -1328,6 +1337,19 @@ namespace {
 constexpr int MAX_DEVICES = 64;
 void* g_scratch_ptr[MAX_DEVICES];
 std::mutex g_scratch_mutex;
+// Every context on a GPU shares that GPU's one array: a call holds it for its whole duration, and a second call that
+// arrives meanwhile (another context, another thread) is refused with RT_ERR_BUSY instead of racing on the queues.
+std::atomic<int> g_scratch_busy[MAX_DEVICES];
+struct ScratchHold {
+    int dev;
+    explicit ScratchHold(int d) : dev(d) {
+        int expected = 0;
+        if (dev < 0 || dev >= MAX_DEVICES || !g_scratch_busy[dev].compare_exchange_strong(expected, 1))
+            throw RtError{RT_ERR_BUSY, "rt_render_accum_device_noalloc: the static work area of this GPU is in use by another call "
+                                       "(every context on a GPU shares it; make the calls one after the other)"};
+    }
+    ~ScratchHold() { g_scratch_busy[dev].store(0); }
+};
 // The address of `scratch` on device `dev`, which must be the current device.
 void* scratch_for_device(int dev) {
     if (dev < 0 || dev >= MAX_DEVICES) return nullptr;
@@ -1558,6 +1580,7 @@ int rt_render_accum_device_noalloc(rt_context* ctx, uint32_t width, uint32_t hei
             throw RtError{RT_ERR_INVALID, "rt_render_accum_device_noalloc: rows [j0, j1) hold " + std::to_string((uint64_t)width * (j1 - j0)) +
                                               " pixels, more than the " + std::to_string(RT_NOALLOC_MAX_PATHS) +
                                               " paths the library's static work area holds; render fewer rows per call"};
+        ScratchHold hold(ctx->device);
         ctx->engine->render_accum(width, height, j0, j1, s0, n_samples, max_bounces, seed, accum_dev, nullptr, true);
     });
 }

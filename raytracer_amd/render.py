@@ -69,7 +69,10 @@ class GpuEngine:
         torch = self.torch
         accums = [torch.zeros((hi - lo) * width * 3, dtype=torch.float64, device=self.device) for _ in self.renderers]
         if n > 0:
-            torch.cuda.synchronize(self.device)  # torch's stream -> the library's streams
+            # torch's stream -> the library's streams.  Only the stream that zeroed the buffers: a device-wide
+            # synchronize would also wait for the band before, whose reduce is still running on RCCL's stream -
+            # the overlap of a band's reduce with the next band's tracing would be gone.
+            torch.cuda.current_stream(self.device).synchronize()
             parts = parallel.render_concurrent(self.renderers, accums, width, height, lo, hi, s0, n, max_bounces, seed)
             self.rays += sum(st.rays for st in parts)
             self.gpu_ms += max(st.ms_total for st in parts)

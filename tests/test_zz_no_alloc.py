@@ -77,3 +77,47 @@ def test_noalloc_in_f32_mode(rt):
     H = scene.image_height(W)
     want, got = _both(rt, r, torch, W, H, 0, H, 0, 9, 8, seed=1)
     assert want.any() and np.array_equal(want, got)
+
+
+def test_two_contexts_on_one_gpu_do_not_share_the_work_area_at_once(rt):
+    # Every context on a GPU carves its buffers from the same static array: calls that overlap are refused (RT_ERR_BUSY = -7)
+    # instead of corrupting each other's queues.  Two contexts, two threads, several rounds: every call either returns the
+    # allocating entry point's sums bit for bit or is refused; calls made one after the other all succeed.
+    import threading
+
+    import torch
+
+    sc = rt.Scene.load(scene_path("cornell"), ROOT)
+    W = 128
+    H = sc.image_height(W)
+    ctxs = [rt.Renderer(0), rt.Renderer(0)]
+    for r in ctxs:
+        r.upload(sc)
+    want = torch.zeros(W * H * 3, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    ctxs[0].render_accum_device(W, H, 0, H, 0, 24, 50, 3, want.data_ptr(), want_stats=False)
+    outcomes = [[], []]
+
+    def worker(k):
+        for _ in range(6):
+            acc = torch.zeros(W * H * 3, dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()
+            try:
+                ctxs[k].render_accum_device_noalloc(W, H, 0, H, 0, 24, 50, 3, acc.data_ptr())
+                outcomes[k].append(bool(torch.equal(acc, want)))
+            except rt.RtError as e:
+                assert e.code == -7 and "in use" in e.message
+                outcomes[k].append(None)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    done = [o for o in outcomes[0] + outcomes[1] if o is not None]
+    assert done and all(done), outcomes          # whatever ran, ran alone and is right
+    for r in ctxs:                               # and one after the other, nothing is refused
+        acc = torch.zeros(W * H * 3, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        r.render_accum_device_noalloc(W, H, 0, H, 0, 24, 50, 3, acc.data_ptr())
+        assert torch.equal(acc, want)
