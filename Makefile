@@ -29,6 +29,10 @@ $(OBJDIR)/kernels_%.o: raytracer_amd/csrc/device/kernels.hip raytracer_amd/csrc/
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DRT_PART=$* -c $< -o $@
 
+$(OBJDIR)/bvh_build.o: raytracer_amd/csrc/device/bvh_build.hip raytracer_amd/csrc/device/rt_device.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(OBJDIR)/capi.o: raytracer_amd/csrc/capi.cpp raytracer_amd/csrc/tree_layout.hpp raytracer_amd/csrc/device/rt_device.h $(HOST_HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -37,7 +41,7 @@ $(OBJDIR)/multi.o: raytracer_amd/csrc/multi.cpp raytracer_amd/csrc/device/rt_dev
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/librt_mi355x.so: $(HOST_OBJS) $(KERNEL_OBJS) $(OBJDIR)/capi.o $(OBJDIR)/multi.o
+$(LIBDIR)/librt_mi355x.so: $(HOST_OBJS) $(KERNEL_OBJS) $(OBJDIR)/bvh_build.o $(OBJDIR)/capi.o $(OBJDIR)/multi.o
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lz -ldl -lpthread
 

@@ -393,6 +393,7 @@ struct Tuning {
     int pixel_blocks = -1;      // RT_PIXEL_BLOCKS=0 rows, 1 blocks of 8 x 8 pixels, 2 forced pixels x samples (-1: by scene)
     uint32_t runahead = 2;      // RT_RUNAHEAD: bounces enqueued beyond the last live count the host has seen
     bool debug = false;         // RT_DEBUG: counts and layout choices on stderr
+    long gpu_build = -1;        // RT_GPU_BUILD=n: meshes of at least n triangles get their four-wide tree built on the GPU (0: never; -1: default)
     static Tuning from_environment() {
         Tuning t;
         auto num = [](const char* name, long fallback) {
@@ -421,9 +422,16 @@ struct Tuning {
         if (const char* e = std::getenv("RT_PIXEL_BLOCKS")) t.pixel_blocks = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
         t.runahead = (uint32_t)std::max(1l, std::min(64l, num("RT_RUNAHEAD", 2)));
         t.debug = std::getenv("RT_DEBUG") != nullptr;
+        t.gpu_build = num("RT_GPU_BUILD", -1);
         return t;
     }
 };
+
+// Meshes of at least this many triangles get their four-wide tree from the GPU builder unless RT_GPU_BUILD says otherwise
+// (0: never).  Measured in DESIGN.md section 6 ("GPU tree build").
+#ifndef RT_GPU_BUILD_DEFAULT_MIN
+#define RT_GPU_BUILD_DEFAULT_MIN 2000000
+#endif
 
 struct EngineBase {
     virtual ~EngineBase() {}
@@ -539,6 +547,56 @@ struct Engine : EngineBase {
             const float pad = box_pad(d);
             S.tlas_root4 = -1;
             stack_need4 = 0;
+            // Meshes of at least `gpu_build_min` triangles get their four-wide tree from the GPU builder (bvh_build.hip:
+            // Morton order, radix tree, fold, quantisation) instead of the host's binned-SAH regrouping; the host still
+            // says which leaves the reference can reach (collect_leaves) and pads their boxes.  A tree that comes out too
+            // deep for the walk's stack, or that the builder cannot store, is built by the host after all.
+            struct GpuTree {
+                int32_t first;  // rt_node root of the mesh
+                rtd::DNode4* nodes;
+                uint32_t n_nodes;
+                int levels;
+            };
+            std::vector<GpuTree> gpu_trees;
+            struct FreeTrees {
+                std::vector<GpuTree>& t;
+                ~FreeTrees() {
+                    for (GpuTree& g : t)
+                        if (g.nodes) (void)hipFree(g.nodes);
+                }
+            } free_trees{gpu_trees};
+            const long gpu_build_min = tune.gpu_build >= 0 ? tune.gpu_build : RT_GPU_BUILD_DEFAULT_MIN;
+            const clock::time_point t_gpu = clock::now();
+            if (tune.bvh4 && d.tlas_root >= 0 && gpu_build_min > 0) {
+                std::vector<char> tried(d.n_nodes, 0);
+                for (uint64_t i = 0; i < d.n_objects; i++) {
+                    if (d.objects[i].kind != RT_OBJ_BLAS || tried[(size_t)d.objects[i].first]) continue;
+                    const int32_t first = d.objects[i].first;
+                    tried[(size_t)first] = 1;
+                    std::vector<float> lo, hi;
+                    std::vector<int32_t> refs;
+                    if ((long)d.n_triangles < gpu_build_min) continue;  // (no mesh of the scene can be that large)
+                    lo.reserve(3 * (size_t)d.n_triangles);
+                    hi.reserve(3 * (size_t)d.n_triangles);
+                    refs.reserve((size_t)d.n_triangles);
+                    if (!collect_leaf_arrays(d, first, pad, lo, hi, refs) || (long)refs.size() < gpu_build_min || refs.empty()) continue;
+                    GpuTree g{first, nullptr, 0, 0};
+                    const int rc = rtd::gpu_build_tree4(lo.data(), hi.data(), refs.data(), (uint32_t)refs.size(), 0, stream, &g.nodes, &g.n_nodes, &g.levels);
+                    if (rc > 0) throw RtError{RT_ERR_DEVICE, std::string("GPU tree build: ") + hipGetErrorString((hipError_t)rc)};
+                    if (rc == 0 && 3 * g.levels + 8 <= lds_part + RT_STACK_OVERFLOW) gpu_trees.push_back(g);
+                    else if (g.nodes) (void)hipFree(g.nodes);
+                    if (tune.debug)
+                        std::fprintf(stderr, "  GPU tree build: %zu leaves -> %u nodes, %d levels%s\n", refs.size(), g.n_nodes, g.levels,
+                                     rc == 0 && 3 * g.levels + 8 <= lds_part + RT_STACK_OVERFLOW ? "" : " (not used: too deep or not storable)");
+                }
+            }
+            up_stats.ms_gpu_build = gpu_trees.empty() ? 0.0 : ms_since(t_gpu);
+            up_stats.gpu_built_trees = (uint32_t)gpu_trees.size();
+            auto gpu_tree_of = [&](int32_t first) -> const GpuTree* {
+                for (const GpuTree& g : gpu_trees)
+                    if (g.first == first) return &g;
+                return nullptr;
+            };
             for (int use_sah = tune.sah == 0 ? 0 : 1; use_sah >= 0; use_sah--) {
                 if (!tune.bvh4 || d.tlas_root < 0) break;
                 std::vector<rtd::WideNode4> v;
@@ -558,7 +616,12 @@ struct Engine : EngineBase {
                 for (uint64_t i = 0; i < d.n_objects; i++)
                     if (d.objects[i].kind == RT_OBJ_BLAS && root4[d.objects[i].first] < 0) {
                         int need_here = 0;
-                        root4[d.objects[i].first] = build(d.objects[i].first, &need_here);
+                        if (const GpuTree* g = gpu_tree_of(d.objects[i].first)) {
+                            root4[d.objects[i].first] = 0;  // (its place follows the host's nodes: set below)
+                            need_here = 3 * g->levels;
+                        } else {
+                            root4[d.objects[i].first] = build(d.objects[i].first, &need_here);
+                        }
                         need = std::max(need, need_here);
                     }
                 stack_need4 = need + need_world + 3;
@@ -570,7 +633,20 @@ struct Engine : EngineBase {
                             std::fprintf(stderr, "  world slot %d: child %d  [%g %g %g] - [%g %g %g]\n", k, w.child[k], w.lo[0][k], w.lo[1][k],
                                          w.lo[2][k], w.hi[0][k], w.hi[1][k], w.hi[2][k]);
                     }
-                    nodes4.upload(packed);
+                    size_t total = packed.size();
+                    for (const GpuTree& g : gpu_trees) total += g.n_nodes;
+                    if (total > 0x7fffffffull) throw RtError{RT_ERR_INVALID, "scene description: too many four-wide nodes"};
+                    nodes4.release();
+                    nodes4.ensure(total);
+                    if (!packed.empty()) HIP_CHECK(hipMemcpy(nodes4.p, packed.data(), packed.size() * sizeof(rtd::DNode4), hipMemcpyHostToDevice));
+                    size_t at = packed.size();
+                    for (const GpuTree& g : gpu_trees) {
+                        rtd::gpu_place_tree4(g.nodes, g.n_nodes, (int32_t)at, nodes4.p + at, stream);
+                        HIP_CHECK(hipGetLastError());
+                        root4[(size_t)g.first] = (int32_t)at;
+                        at += g.n_nodes;
+                    }
+                    HIP_CHECK(hipStreamSynchronize(stream));
                     S.nodes4 = nodes4.p;
                     sah_trees = use_sah != 0;
                     break;

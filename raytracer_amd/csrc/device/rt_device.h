@@ -299,4 +299,14 @@ void launch_scan_tiles(const uint32_t* tile_counts, uint32_t n_tiles, uint32_t* 
                        uint32_t* counts, unsigned long long* ray_total, uint32_t* host_total, hipStream_t st);
 void launch_quantize(const double* accum, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb8, hipStream_t st);
 
+// bvh_build.hip: the four-wide tree over n >= 1 leaves built on the GPU (Morton order, binary radix tree, bottom-up
+// boxes, fold to four children, 8-bit quantisation).  lo / hi: the leaves' padded f32 boxes [n][3] (host), refs: a
+// leaf's child reference (host).  *nodes_out: device array of *n_nodes DNode4 that the caller frees with hipFree,
+// node 0 the super-root, child references = index_base + position in the array; *levels: four-wide levels.
+// Returns 0, a hipError_t (> 0), or -1 when the boxes cannot be stored (the caller keeps the host's tree).
+int gpu_build_tree4(const float* lo, const float* hi, const int32_t* refs, uint32_t n, int32_t index_base, hipStream_t st,
+                    DNode4** nodes_out, uint32_t* n_nodes, int* levels);
+// Copies such a tree (built with index_base = 0) to dst, its child references moved by `offset` (= dst's index in the scene's array).
+void gpu_place_tree4(const DNode4* src, uint32_t n, int32_t offset, DNode4* dst, hipStream_t st);
+
 }  // namespace rtd

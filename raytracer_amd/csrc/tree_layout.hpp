@@ -234,6 +234,33 @@ inline bool collect_leaves(const rt_scene_desc& d, int32_t root, float pad, std:
     }
     return true;
 }
+// The same leaves as flat arrays (what the GPU builder takes: bvh_build.hip): padded boxes [n][3] and child references.
+inline bool collect_leaf_arrays(const rt_scene_desc& d, int32_t root, float pad, std::vector<float>& lo, std::vector<float>& hi,
+                                std::vector<int32_t>& refs) {
+    lo.clear();
+    hi.clear();
+    refs.clear();
+    std::vector<int32_t> todo{root};
+    while (!todo.empty()) {
+        const rt_node& nd = d.nodes[todo.back()];
+        todo.pop_back();
+        if (nd.left >= 0) {
+            if (dead_interior(nd)) continue;
+            todo.push_back(nd.right);
+            todo.push_back(nd.left);
+            continue;
+        }
+        float blo[3], bhi[3];
+        padded_box(nd, pad, blo, bhi);
+        for (int k = 0; k < 3; k++) {
+            if (!std::isfinite(blo[k]) || !std::isfinite(bhi[k])) return false;
+            lo.push_back(blo[k]);
+            hi.push_back(bhi[k]);
+        }
+        refs.push_back(nd.left);
+    }
+    return true;
+}
 inline double box_area(const float* lo, const float* hi) {
     const double e0 = (double)hi[0] - lo[0], e1 = (double)hi[1] - lo[1], e2 = (double)hi[2] - lo[2];
     return e0 * e1 + e1 * e2 + e2 * e0;

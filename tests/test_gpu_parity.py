@@ -337,6 +337,9 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_COOP": "32"}),                         # groups of two lanes and up
         ("knight", {"RT_COOP": "32", "RT_FEATURES": "all"}),
         ("knight", {"RT_COOP": "32", "RT_STACK_CAP": "20"}),   # a frontier with little room: mostly one entry a round
+        ("knight", {"RT_GPU_BUILD": "1"}),                     # the mesh's four-wide tree from the GPU builder (Morton order, radix tree, fold)
+        ("knight", {"RT_GPU_BUILD": "1", "RT_COOP": "32"}),
+        ("knight", {"RT_GPU_BUILD": "1", "RT_ORDERED": "0", "RT_FEATURES": "all"}),
     ],
 )
 def test_traversal_layouts_agree_bit_for_bit(rt, gpu_scenes, name, env, monkeypatch):
@@ -352,6 +355,8 @@ def test_traversal_layouts_agree_bit_for_bit(rt, gpu_scenes, name, env, monkeypa
         monkeypatch.setenv(k, v)
     other = rt.Renderer(device=0, precision=0)
     other.upload(sc)
+    if "RT_GPU_BUILD" in env:
+        assert other.upload_stats().gpu_built_trees == 1 and default_renderer.upload_stats().gpu_built_trees == 0
     rgb8_b, sums_b, st_b = other.render_rows(W, H, 0, H, 8, 20, seed=77)
     hits_b = other.trace(rays, seed=5)
     assert st_a.rays == st_b.rays
@@ -486,18 +491,23 @@ def _corners_scene(tmp, with_mesh, extra_spheres, nested=False):
     }""" % (objs, ", ".join('"%s"' % w for w in world))
 
 
-@pytest.mark.parametrize("with_mesh,extra_spheres,nested", [(False, 0, False), (False, 14, False), (False, 150, False), (True, 0, False),
-                                                           (True, 150, False), (False, 0, True), (True, 150, True)])
-def test_every_object_kind_against_the_oracle(rt, orc, tmp_path, with_mesh, extra_spheres, nested):
+@pytest.mark.parametrize("with_mesh,extra_spheres,nested,gpu_build", [(False, 0, False, False), (False, 14, False, False), (False, 150, False, False),
+                                                                     (True, 0, False, False), (True, 150, False, False), (False, 0, True, False),
+                                                                     (True, 150, True, False), (True, 0, False, True), (True, 150, True, True)])
+def test_every_object_kind_against_the_oracle(rt, orc, tmp_path, monkeypatch, with_mesh, extra_spheres, nested, gpu_build):
     # (False, 0): a world of 7 leaves is swept; (False, 14): own-box tree staged in LDS; (False, 150): too large
     # for LDS - four-wide world tree, k_extend_refill with media; (True, ..): meshes and media together - the
     # general four-wide kernel, a medium bounded by a mesh; nested: media bounded by media (plain and behind
-    # transforms), which only the general four-wide kernel answers - a small world takes it too then
+    # transforms), which only the general four-wide kernel answers - a small world takes it too then; gpu_build: the
+    # four-triangle mesh's tree comes from the GPU builder (csrc/device/bvh_build.hip: one fold level, leaves only)
+    if gpu_build:
+        monkeypatch.setenv("RT_GPU_BUILD", "1")
     text = _corners_scene(str(tmp_path), with_mesh, extra_spheres, nested)
     scene = rt.Scene.from_text(text)
     o = orc.OracleScene.from_text(text)
     r = rt.Renderer(0)
     r.upload(scene)
+    assert r.upload_stats().gpu_built_trees == (1 if gpu_build else 0)
     W = 96
     H = scene.image_height(W)
     assert H == o.image_height(W)
