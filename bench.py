@@ -454,7 +454,7 @@ def main() -> None:
     ap.add_argument("--strong", action="store_true", help="strong scaling: --spp is the whole image's sample count, split over the GPUs (the default for N > 1)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: --spp samples per GPU, an N x spp image")
     args = ap.parse_args()
-    args.strong = args.strong or (args.gpus > 1 and not args.weak) or int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.weak
+    args.strong = not args.weak  # (one GPU: the same image either way - labelled like the N > 1 lines it is compared with)
 
     if args.overlap > 1:  # two streams share the CUs: 8 persistent blocks per CU each measure best
         os.environ.setdefault("RT_GRID_MULT", "8")

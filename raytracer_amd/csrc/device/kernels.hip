@@ -872,17 +872,31 @@ __device__ bool simple_object_hit(const DScene<T>& S, int oi, const Ray<T>& worl
 // The stream of a path's draws is named by (pixel, sample); both come from the path id by an
 // integer division, which only the rare constant-medium draw needs: computed there.
 struct PathRef {
-    const DBatch* batch;
+    // What names a path's random streams, by value: holding a pointer to the kernel's DBatch argument instead made the
+    // compiler keep that argument in scratch memory (its address escaped into the out-of-line draw below), and with it
+    // everything derived from the seed - the ten round keys of every Philox block - lived in per-lane registers.
+    uint64_t seed;
+    uint32_t npix, width, j0, s0, trace_mode;
     uint32_t pid;
 };
+__device__ __forceinline__ PathRef path_of(const DBatch& B, uint32_t pid) {
+    return PathRef{B.seed, B.npix, B.width, B.j0, B.s0, B.trace_mode, pid};
+}
 
 // ln(xi) of the constant-medium draw (src/objects.rs:428-429).  Out of line: f64 log and the stream
 // set-up are rare and would otherwise keep their constants live across the whole traversal loop.
 template <typename T>
 __device__ __noinline__ T medium_log_draw(PathRef path, uint32_t rng_key, uint32_t depth) {
-    uint32_t pixel, sample;
-    path_ids(*path.batch, path.pid, &pixel, &sample);
-    Rng<T> rng(path.batch->seed, DOMAIN_MEDIUM | rng_key, pixel, sample, depth);
+    uint32_t pixel, sample;  // (path_ids, from the fields the reference carries)
+    if (path.trace_mode) {
+        pixel = path.s0 + path.pid;
+        sample = 0;
+    } else {
+        const uint32_t pl = path.pid % path.npix, sl = path.pid / path.npix;
+        pixel = path.j0 * path.width + pl;
+        sample = path.s0 + sl;
+    }
+    Rng<T> rng(path.seed, DOMAIN_MEDIUM | rng_key, pixel, sample, depth);
     return log(rng.next());
 }
 
@@ -1556,7 +1570,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DScene<T> S, 
         uint32_t tile;
         const uint32_t i = slot_of(tile_offsets, n_tiles, d, base, &tile);
         Ray<T> r = load_ray(q, i);
-        const PathRef path{&B, q.pid[i]};
+        const PathRef path = path_of(B, q.pid[i]);
         T min_dist = tmin_arr ? tmin_arr[i] : (T)0.001;  // src/hitting.rs:20-21
         T max_dist = tmax_arr ? tmax_arr[i] : Lim<T>::inf();
         T t;
@@ -1731,7 +1745,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend_refill(DScene
         if (walking == 0 || (uint32_t)__popcll(__ballot(state == DONE)) >= refill) {
             if (state == DONE) {
                 // the rest of world.hit: the unbounded objects of the top-level list, in its order (src/hitting.rs:88-104)
-                const PathRef path{&B, pid};
+                const PathRef path = path_of(B, pid);
                 const T max_dist = tmax_arr ? tmax_arr[slot] : Lim<T>::inf();
                 bool have = false;
                 T best_t = 0;
@@ -1816,7 +1830,7 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend_refill(DScene
                 walk.node(S, st);
             }
         }
-        if (state == WALK) walk.leaf(S, st, PathRef{&B, pid}, depth);
+        if (state == WALK) walk.leaf(S, st, path_of(B, pid), depth);
     }
 }
 
@@ -2078,7 +2092,7 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
     // (known != nullptr: the closest-hit query has been answered already, by the lane's group)
     struct Answer { bool hit; T t; Winner w; };
     auto bounce_once = [&](const Ray<T>& ray, V3<T>& thr, uint32_t pid, uint32_t depth, Ray<T>& nr, const Answer* known = nullptr) -> bool {
-        const PathRef path{&B, pid};
+        const PathRef path = path_of(B, pid);
         T t = 0, u = 0, v = 0;
         V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
         uint32_t mf = RT_MISS;
@@ -2190,7 +2204,7 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
                     if (has_ray) {
                         GroupStack gs;
                         gs.base = st.base; gs.stride = st.stride; gs.cap = st.cap; gs.overflow = st.overflow; gs.group = G;
-                        g_hit = closest_hit<T, MODE>(W, gr, (T)0.001, Lim<T>::inf(), gs, PathRef{&B, g_pid}, g_depth, &g_t, &g_w);
+                        g_hit = closest_hit<T, MODE>(W, gr, (T)0.001, Lim<T>::inf(), gs, path_of(B, g_pid), g_depth, &g_t, &g_w);
                     }
                     // back to the path's own lane: the k-th live lane reads lane 0 of group k
                     const int from = __popcll(live & ((1ull << lane) - 1ull)) * G;
@@ -2361,7 +2375,7 @@ __global__ void __launch_bounds__(BLOCK) k_second(DScene<T> S, DBatch B, DQueue<
     const Ray<T> r = load_ray(q, i);
     Second<T> sc{inf, tmin_arr[i], h.owner[i], h.sub[i]};
     const float shift = far_shift(S, r);
-    const PathRef path{&B, q.pid[i]};
+    const PathRef path = path_of(B, q.pid[i]);
     for (int e = 0; e < S.n_top; e++) {
         const int entry = S.top_list[e];
         if (entry != RT_TOP_BVH) object_candidates(S, entry, r, st, 0, shift, path, sc);
