@@ -312,6 +312,7 @@ def run_workload(args, scene_name, steps, warmup, torch, rt, parallel, dist, ran
     n_extend, n_shade, n_tail = int(last.extend_launches), int(last.shade_launches), int(last.tail_launches)
     fused = last.extend_kernel == 2
     kernel = "k_bounce" if fused else "k_extend_refill" if last.extend_kernel == 1 else "k_extend"
+    walk_kernel = kernel  # (the kernel that walks the scene: SURVEY 8d's nominal flops and touched bytes are its)
     rays_nontail = rays_step - rays_tail
     # Algorithmic (compulsory) HBM bytes per kernel and step: queue entries and hit records are read /
     # written once per ray, the scene once per launch.  The records a traversal touches again and again (SURVEY.md 8d's
@@ -359,8 +360,14 @@ def run_workload(args, scene_name, steps, warmup, torch, rt, parallel, dist, ran
                 priced.append(price_kernel(name, pmc["kernels"][name], ms, n, compulsory[name], f64_clock))
         for e in priced:
             e["share_of_instrumented_step"] = e["ms"] / float(last.ms_total) if last.ms_total else None
-    dom = next((e for e in priced if e["kernel"] == kernel), None)
-    if dom is not None and "issue_frac" in dom:
+    # the top-level fields describe the kernel that takes the largest part of the step (two_spheres: k_shade, not k_extend)
+    dom = max((e for e in priced if "issue_frac" in e), key=lambda e: e["ms"], default=None)
+    if dom is not None:
+        kernel, n_extend = dom["kernel"], dom["launches"]
+        ms_per_launch = dom["avg_launch_ms"]
+        rays_per_launch = dom["rays"] / max(n_extend, 1)
+        hbm.update({"achieved": dom["hbm_GBps"], "frac": dom["hbm_frac"], "bytes_per_launch": dom["hbm_compulsory_bytes"] / max(n_extend, 1),
+                    "bytes_per_ray": dom["hbm_compulsory_bytes"] / max(dom["rays"], 1.0)})
         hbm["traffic"] = dom.get("traffic_bytes", 0.0) / max(n_extend, 1) if "traffic_bytes" in dom else None
         # every kernel of the step, launches and all (raygen, accumulate, scans included), against the step's wall time
         whole_low = sum(issue_cycles(k["counters"])[0] for k in pmc["kernels"].values())
@@ -407,7 +414,7 @@ def run_workload(args, scene_name, steps, warmup, torch, rt, parallel, dist, ran
             "wall_clock_per_image_s": dt / steps, "seed": args.seed, "concurrent_batches_per_gpu": K, "lanes": args.lanes,
         },
         "roofline": roofline,
-        "roofline_valu": {"kernel": kernel, "achieved": flops, "peak": valu_peak, "unit": "TFLOP/s", "frac": flops / valu_peak,
+        "roofline_valu": {"kernel": walk_kernel, "achieved": flops, "peak": valu_peak, "unit": "TFLOP/s", "frac": flops / valu_peak,
                           "note": "SURVEY 8d's nominal flops (21 per box, 17 rect, 25 sphere, 52 triangle): counts neither divisions as sequences nor addressing"},
         # the extra, instrumented step (one lane, events on): what the per-kernel prices are made of.  Its launches add up to
         # less than its own GPU time; ms_per_step above is the product's schedule (two lanes where they pay) and is not its mean.

@@ -1860,13 +1860,36 @@ __device__ __noinline__ T reflectance(T cosine, T ref_idx) {  // src/materials.r
 
 // Checkered::{emitted, scatter} (src/materials.rs:166-183) pick a part by the sign of
 // sin(k f u) sin(k f v), f = PI in scatter and 1 in emitted, possibly through nested checkers.
-// Out of line: f64 sin carries a large argument reduction that would otherwise sit in every kernel.
+// Only the SIGN of each sine is needed, and sin(x) = (-1)^n sin(x - n pi) with |x - n pi| <= pi / 2 has the sign of
+// (-1)^n (x - n pi): found from the place of x among the multiples of pi (two-term pi, fused steps) in a dozen
+// instructions instead of two f64 sines of ~100 each.  Where that place is not safely decided - x within 1e-12 |n| of a
+// multiple, huge, tiny, not finite - or where a product of two tiny sines could underflow, the sines themselves are
+// taken (out of line: f64 sin carries a large argument reduction that would otherwise sit in every kernel), so the part
+// chosen is always the one `sines < 0` chooses.
 template <typename T>
-__device__ __noinline__ int resolve_checkered(const DScene<T>& S, int mi, T u, T v, T f) {
+__device__ __noinline__ bool checker_is_odd_by_sines(T a, T b) {
+    return sin(a) * sin(b) < (T)0.0;
+}
+// +1 / -1: the sign of sin(x); 0: undecided here
+__device__ __forceinline__ int sin_sign(double x) {
+    const double ax = fabs(x);
+    if (!(ax < 1e15) || ax < 1e-100) return 0;
+    const double n = rint(x * 0.31830988618379067154);
+    double r = fma(-n, 3.141592653589793116, x);     // pi = 0x1.921fb54442d18p+1 + 0x1.1a62633145c07p-53 + ...
+    r = fma(-n, 1.2246467991473532072e-16, r);
+    if (!(fabs(r) > 1e-12 * fmax(1.0, fabs(n)))) return 0;
+    const bool odd = ((long long)n & 1LL) != 0;
+    return ((r > 0.0) != odd) ? 1 : -1;
+}
+__device__ __forceinline__ int sin_sign(float) { return 0; }  // (fast mode: the sines themselves)
+template <typename T>
+__device__ __forceinline__ int resolve_checkered(const DScene<T>& S, int mi, T u, T v, T f) {
     DMaterial<T> m = S.materials[mi];
     while (m.type == RT_MAT_CHECKERED) {
-        T sines = sin(m.param * f * u) * sin(m.param * f * v);
-        mi = sines < (T)0.0 ? m.odd : m.even;
+        const T a = m.param * f * u, b = m.param * f * v;
+        const int sa = sin_sign(a), sb = sin_sign(b);
+        const bool odd = (sa != 0 && sb != 0) ? (sa != sb) : checker_is_odd_by_sines(a, b);
+        mi = odd ? m.odd : m.even;
         m = S.materials[mi];
     }
     return mi;
