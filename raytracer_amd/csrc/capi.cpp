@@ -393,6 +393,7 @@ struct Tuning {
     int pixel_blocks = -1;      // RT_PIXEL_BLOCKS=0 rows, 1 blocks of 8 x 8 pixels, 2 forced pixels x samples (-1: by scene)
     uint32_t runahead = 2;      // RT_RUNAHEAD: bounces enqueued beyond the last live count the host has seen
     bool debug = false;         // RT_DEBUG: counts and layout choices on stderr
+    bool fuse_raygen = true;    // RT_FUSE_RAYGEN=0: k_raygen writes the camera rays of a batch to its queue also where the first bounce could make them
     long gpu_build = -1;        // RT_GPU_BUILD=n: meshes of at least n triangles get their four-wide tree built on the GPU (0: never; -1: default)
     static Tuning from_environment() {
         Tuning t;
@@ -422,6 +423,7 @@ struct Tuning {
         if (const char* e = std::getenv("RT_PIXEL_BLOCKS")) t.pixel_blocks = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
         t.runahead = (uint32_t)std::max(1l, std::min(64l, num("RT_RUNAHEAD", 2)));
         t.debug = std::getenv("RT_DEBUG") != nullptr;
+        t.fuse_raygen = !is("RT_FUSE_RAYGEN", '0');
         t.gpu_build = num("RT_GPU_BUILD", -1);
         return t;
     }
@@ -1107,6 +1109,7 @@ struct Engine : EngineBase {
     struct BatchRun {
         bool active = false;
         uint32_t index = 0, bs0 = 0, bns = 0, n_paths = 0, n_tiles = 0, depth = 0, known_depth = 0, known_alive = 0;
+        bool first_fused = false;  // the first bounce makes its own camera rays (k_bounce<.., FIRST = true>): no k_raygen, queue 0 never written
         rtd::DBatch B;
     };
     struct LaneRun {
@@ -1246,6 +1249,15 @@ struct Engine : EngineBase {
                 for (uint32_t k = 0; k < PEEK_SLOTS; k++) L.peek[L.ring * PEEK_SLOTS + k] = PEEK_UNKNOWN;
                 __atomic_thread_fence(__ATOMIC_SEQ_CST);
                 HIP_CHECK(hipMemsetAsync(w.sample_rgb, 0, (size_t)b.n_paths * 3 * sizeof(T), st));
+                // Sweep scenes (one fused launch per bounce): the first bounce makes the camera rays itself - 84 B per path
+                // neither written nor read, one launch fewer (cornell 0.65 ms of 19.5, globe of 3.0) - unless the batch is
+                // small enough to start in the tail launch, which reads a queue.
+                b.first_fused = fused && tune.fuse_raygen && max_bounces > 0 && b.n_paths > tail_threshold && S.n_sweep > 0;
+                if (b.first_fused) {
+                    // the totals of the (unwritten) dense queue 0, clear the counts of queue 1, rays += n_paths
+                    rtd::launch_scan_tiles(nullptr, b.n_tiles, w.tile_offsets, w.tile_counts[1], w.counts, w.ray_total, nullptr, st, b.n_paths);
+                    return STEP_PROGRESS;
+                }
                 rtd::Launch<T>::raygen(S, b.B, queue(w, 0), b.n_paths, w.tile_counts[0], st);
                 // offsets of queue 0, clear the counts of queue 1, rays += n_paths (if any bounce runs)
                 rtd::launch_scan_tiles(w.tile_counts[0], b.n_tiles, w.tile_offsets, w.tile_counts[1], w.counts,
@@ -1276,7 +1288,7 @@ struct Engine : EngineBase {
                     HIP_CHECK(hipEventRecord(L.event(R.ev), st));
                 }
                 rtd::Launch<T>::bounce(S, small, b.B, queue(w, in), queue(w, out), w.sample_rgb, depth, max_bounces, w.tile_offsets,
-                                       w.tile_counts[out], b.n_tiles, stack_depth, tail_grid_for(b.known_alive), &tail, st);
+                                       w.tile_counts[out], b.n_tiles, stack_depth, tail_grid_for(b.known_alive), &tail, 0u, st);
                 if (timing) HIP_CHECK(hipEventRecord(L.event(R.ev + 1), st));
                 R.ev += 3;
                 b.depth = max_bounces;  // nothing is left after it
@@ -1292,7 +1304,7 @@ struct Engine : EngineBase {
             }
             if (fused) {  // one launch per bounce; its time is reported as ms_extend
                 rtd::Launch<T>::bounce(S, small, b.B, queue(w, in), queue(w, out), w.sample_rgb, depth, max_bounces, w.tile_offsets,
-                                       w.tile_counts[out], b.n_tiles, stack_depth, grid, nullptr, st);
+                                       w.tile_counts[out], b.n_tiles, stack_depth, grid, nullptr, depth == 0 && b.first_fused ? b.n_paths : 0u, st);
                 if (timing) HIP_CHECK(hipEventRecord(L.event(R.ev + 1), st));
             } else {
                 launch_extend(w, st, b.B, queue(w, in), hits(w, false), nullptr, nullptr, depth, b.n_tiles, grid);

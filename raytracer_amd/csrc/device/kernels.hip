@@ -1422,10 +1422,24 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_tiles(const uint32_t* __r
                                                               uint32_t* __restrict__ counts_to_zero,
                                                               uint32_t* __restrict__ total_out,
                                                               unsigned long long* __restrict__ ray_total,
-                                                              uint32_t* __restrict__ host_total) {
+                                                              uint32_t* __restrict__ host_total, uint32_t dense_total) {
     __shared__ uint32_t partial[SCAN_THREADS];
     const uint32_t per = (n_tiles + SCAN_THREADS - 1) / SCAN_THREADS;
     const uint32_t begin = min(n_tiles, threadIdx.x * per), end = min(n_tiles, begin + per);
+    if (tile_counts == nullptr) {
+        // a dense queue of dense_total entries that nobody has written yet (the first bounce makes its own camera rays):
+        // its totals and the zeroing of the other queue's counts, no offsets
+        for (uint32_t t = begin; t < end; t++)
+            if (counts_to_zero) counts_to_zero[t] = 0;
+        if (threadIdx.x == SCAN_THREADS - 1) {
+            total_out[0] = dense_total;
+            total_out[1] = 0;
+            total_out[3] = 0;
+            if (ray_total) *ray_total += dense_total;
+            if (host_total) __hip_atomic_store(host_total, dense_total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     uint32_t sum = 0;
     for (uint32_t t = begin; t < end; t++) sum += tile_counts[t];
     partial[threadIdx.x] = sum;
@@ -1455,12 +1469,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_tiles(const uint32_t* __r
 }
 #endif
 
+// The camera ray of the path that sits in queue slot `slot` of a batch of n_paths (src/main.rs:132-135,
+// Camera::find_ray src/camera.rs:67-75), and the path's id.  The slot -> path mapping is the order of the queue
+// (DBatch::blocked); the path's id, which its random streams are keyed by, does not depend on it.
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<T> q, uint32_t n_paths,
-                                                   uint32_t* tile_counts) {
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;  // place in the queue
-    if (slot >= n_paths) return;
-    if (slot % TILE == 0) tile_counts[slot / TILE] = min(TILE, n_paths - slot);
+__device__ __forceinline__ Ray<T> primary_ray(const DScene<T>& S, const DBatch& B, uint32_t slot, uint32_t n_paths, uint32_t* pid_out) {
     uint32_t pid = slot;
     if (B.blocked == 2u) {
         // A wave = 64 / n neighbouring pixels x n samples of each, n the largest power of two (<= 64) that the batch's
@@ -1516,6 +1529,18 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<
     r.o = ld3(c.origin) + offset;
     r.d = unit_vector(ld3(c.lower_left_corner) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin) - offset);
     r.time = rng.range(c.start_time, c.end_time);
+    *pid_out = pid;
+    return r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_raygen(DScene<T> S, DBatch B, DQueue<T> q, uint32_t n_paths,
+                                                   uint32_t* tile_counts) {
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;  // place in the queue
+    if (slot >= n_paths) return;
+    if (slot % TILE == 0) tile_counts[slot / TILE] = min(TILE, n_paths - slot);
+    uint32_t pid;
+    const Ray<T> r = primary_ray(S, B, slot, n_paths, &pid);
     store_ray(q, slot, r);
     q.tr()[slot] = (T)1.0; q.tg()[slot] = (T)1.0; q.tb()[slot] = (T)1.0;
     q.pid[slot] = pid;
@@ -2093,11 +2118,14 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DScene<T> S, DB
 // register spills of the lean kernel.
 // CAN_TAIL = true is the tail launch in the product (a few thousand waves, fewer than two per SIMD): it is
 // compiled for 2 waves per SIMD, i.e. up to 256 VGPRs, so that the walk + shading of a tree scene does not spill.
-template <typename T, int STACK, int MODE, bool CAN_TAIL>
+// FIRST = true (the first bounce of a batch on the fused path): the camera rays are made here instead of being
+// read from a queue k_raygen has written - 84 B per path that are neither written nor read, and one launch fewer
+// (cornell: k_raygen was 0.65 ms of a 19.5 ms image, globe: of 3.0 ms).  Slot d of the dense batch is path d's place.
+template <typename T, int STACK, int MODE, bool CAN_TAIL, bool FIRST = false>
 __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND_WAVES) k_bounce(DScene<T> S, DSmallScene small, DBatch B, DQueue<T> qin, DQueue<T> qout,
                                                                     T* sample_rgb, uint32_t depth0, uint32_t max_bounces,
                                                                     const uint32_t* __restrict__ tile_offsets,
-                                                                    uint32_t* tile_counts_out, uint32_t n_tiles, DTail tail) {
+                                                                    uint32_t* tile_counts_out, uint32_t n_tiles, DTail tail, uint32_t n_first) {
     __shared__ int32_t lds_stack[STACK * BLOCK];
     constexpr bool LDS_SCENE = MODE == WALK_OWN_BOX_LDS;
     __shared__ uint4 lds_scene[LDS_SCENE ? RT_LDS_SCENE_BYTES / 16 : 1];
@@ -2110,7 +2138,7 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
     DScene<T> W = S;  // the traversal's view of the scene (records in LDS for small worlds)
     if (LDS_SCENE) stage_small_scene(W, small, lds_scene);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t total = tile_offsets[n_tiles];
+    const uint32_t total = FIRST ? n_first : tile_offsets[n_tiles];
     // One bounce of one path: the closest-hit query, the hit record, the shading.
     // (known != nullptr: the closest-hit query has been answered already, by the lane's group)
     struct Answer { bool hit; T t; Winner w; };
@@ -2138,16 +2166,25 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
             const uint32_t d = base + lane;
             const bool valid = d < total;
             uint32_t tile = 0;
-            const uint32_t i = valid ? slot_of(tile_offsets, n_tiles, d, base, &tile) : 0u;
             bool alive = false;
             Ray<T> nr;
             V3<T> thr;
             uint32_t pid = 0;
-            if (valid) {
-                const Ray<T> ray = load_ray(qin, i);
-                pid = qin.pid[i];
-                thr = mk(qin.tr()[i], qin.tg()[i], qin.tb()[i]);
-                alive = bounce_once(ray, thr, pid, depth0, nr);
+            if constexpr (FIRST) {
+                tile = d / TILE;
+                if (valid) {
+                    const Ray<T> ray = primary_ray(S, B, d, total, &pid);
+                    thr = mk((T)1.0, (T)1.0, (T)1.0);
+                    alive = bounce_once(ray, thr, pid, depth0, nr);
+                }
+            } else {
+                const uint32_t i = valid ? slot_of(tile_offsets, n_tiles, d, base, &tile) : 0u;
+                if (valid) {
+                    const Ray<T> ray = load_ray(qin, i);
+                    pid = qin.pid[i];
+                    thr = mk(qin.tr()[i], qin.tg()[i], qin.tb()[i]);
+                    alive = bounce_once(ray, thr, pid, depth0, nr);
+                }
             }
             compact_store(alive, tile, nr, thr, pid, qout, tile_counts_out);
         }
@@ -2550,16 +2587,18 @@ void Launch<T>::extend(const DScene<T>& S, const DSmallScene& small, const DBatc
 template <typename T>
 void Launch<T>::bounce(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> qin, DQueue<T> qout, T* sample_rgb,
                        uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets, uint32_t* tile_counts_out,
-                       uint32_t n_tiles, int stack, int grid_blocks, const DTail* tail, hipStream_t st) {
+                       uint32_t n_tiles, int stack, int grid_blocks, const DTail* tail, uint32_t n_first, hipStream_t st) {
     const DTail tl = tail ? *tail : DTail{nullptr, nullptr};
-#define RT_BOUNCE_(STACK, MODE, CAN_TAIL)                                                                                 \
-    hipLaunchKernelGGL((k_bounce<T, STACK, MODE, CAN_TAIL>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, qin, qout, sample_rgb, \
-                       depth, max_bounces, tile_offsets, tile_counts_out, n_tiles, tl)
-#define RT_BOUNCE(STACK, MODE) RT_BOUNCE_(STACK, MODE, true)
-#define RT_BOUNCE_SWEEP(STACK, MODE)              \
-    do {                                          \
-        if (tail) RT_BOUNCE_(STACK, MODE, true);  \
-        else RT_BOUNCE_(STACK, MODE, false);      \
+    // n_first > 0: the first bounce of a dense batch of n_first paths, camera rays made in the kernel (sweep scenes, no tail)
+#define RT_BOUNCE_(STACK, MODE, CAN_TAIL, FIRST)                                                                                 \
+    hipLaunchKernelGGL((k_bounce<T, STACK, MODE, CAN_TAIL, FIRST>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, qin, qout, sample_rgb, \
+                       depth, max_bounces, tile_offsets, tile_counts_out, n_tiles, tl, n_first)
+#define RT_BOUNCE(STACK, MODE) RT_BOUNCE_(STACK, MODE, true, false)
+#define RT_BOUNCE_SWEEP(STACK, MODE)                            \
+    do {                                                        \
+        if (tail) RT_BOUNCE_(STACK, MODE, true, false);         \
+        else if (n_first) RT_BOUNCE_(STACK, MODE, false, true); \
+        else RT_BOUNCE_(STACK, MODE, false, false);             \
     } while (0)
     if (S.n_sweep > 0 && S.lean) RT_BOUNCE_SWEEP(1, WALK_SWEEP_LEAN);
     else if (S.n_sweep > 0 && stack <= 16) RT_BOUNCE_SWEEP(16, WALK_SWEEP);
@@ -2612,8 +2651,8 @@ void Launch<T>::store_rays(DQueue<T> q, uint32_t n, double* rays9, hipStream_t s
 }
 #if RT_PART_HAS(2)
 void launch_scan_tiles(const uint32_t* tile_counts, uint32_t n_tiles, uint32_t* tile_offsets, uint32_t* counts_to_zero,
-                       uint32_t* total_out, unsigned long long* ray_total, uint32_t* host_total, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, st, tile_counts, n_tiles, tile_offsets, counts_to_zero, total_out, ray_total, host_total);
+                       uint32_t* total_out, unsigned long long* ray_total, uint32_t* host_total, hipStream_t st, uint32_t dense_total) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, st, tile_counts, n_tiles, tile_offsets, counts_to_zero, total_out, ray_total, host_total, dense_total);
 }
 void launch_quantize(const double* accum, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb8, hipStream_t st) {
     uint64_t n = n_pixels * 3;
@@ -2627,7 +2666,7 @@ void launch_quantize(const double* accum, uint64_t n_pixels, uint32_t spp_total,
                                     uint32_t, const uint32_t*, uint32_t, int, int, uint32_t*, int, hipStream_t);
 #define RT_INST_BOUNCE(T)                                                                                                     \
     template void Launch<T>::bounce(const DScene<T>&, const DSmallScene&, const DBatch&, DQueue<T>, DQueue<T>, T*, uint32_t, \
-                                    uint32_t, const uint32_t*, uint32_t*, uint32_t, int, int, const DTail*, hipStream_t);
+                                    uint32_t, const uint32_t*, uint32_t*, uint32_t, int, int, const DTail*, uint32_t, hipStream_t);
 #define RT_INST_REST(T)                                                                                                          \
     template void Launch<T>::raygen(const DScene<T>&, const DBatch&, DQueue<T>, uint32_t, uint32_t*, hipStream_t);                \
     template void Launch<T>::shade(const DScene<T>&, const DBatch&, DQueue<T>, DHits<T>, DQueue<T>, T*, uint32_t, uint32_t,       \

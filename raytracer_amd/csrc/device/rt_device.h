@@ -279,7 +279,7 @@ struct Launch {
     static void bounce(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> qin, DQueue<T> qout,
                        T* sample_rgb, uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets,
                        uint32_t* tile_counts_out, uint32_t n_tiles, int stack, int grid_blocks, const DTail* tail,
-                       hipStream_t st);
+                       uint32_t n_first /* > 0: first bounce of a dense batch of n_first paths, camera rays made in the kernel */, hipStream_t st);
     static void shade(const DScene<T>& S, const DBatch& B, DQueue<T> qin, DHits<T> h, DQueue<T> qout, T* sample_rgb,
                       uint32_t depth, uint32_t max_bounces, const uint32_t* tile_offsets, uint32_t* tile_counts_out,
                       uint32_t n_tiles, int grid_blocks, hipStream_t st);
@@ -295,8 +295,9 @@ struct Launch {
 // Exclusive scan of per-tile counts -> tile_offsets[0..n_tiles]; zeroes counts_to_zero[0..n_tiles) if
 // non-null; counts[0] = total, counts[1] = counts[3] = 0 (the cursors of the next launch); *ray_total += total
 // if non-null; *host_total = total (pinned host memory, system-scope store) if non-null.
+// tile_counts == nullptr: the queue is a dense one of dense_total entries that has not been written (no offsets are made).
 void launch_scan_tiles(const uint32_t* tile_counts, uint32_t n_tiles, uint32_t* tile_offsets, uint32_t* counts_to_zero,
-                       uint32_t* counts, unsigned long long* ray_total, uint32_t* host_total, hipStream_t st);
+                       uint32_t* counts, unsigned long long* ray_total, uint32_t* host_total, hipStream_t st, uint32_t dense_total = 0);
 void launch_quantize(const double* accum, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb8, hipStream_t st);
 
 // bvh_build.hip: the four-wide tree over n >= 1 leaves built on the GPU (Morton order, binary radix tree, bottom-up

@@ -337,6 +337,10 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_COOP": "32"}),                         # groups of two lanes and up
         ("knight", {"RT_COOP": "32", "RT_FEATURES": "all"}),
         ("knight", {"RT_COOP": "32", "RT_STACK_CAP": "20"}),   # a frontier with little room: mostly one entry a round
+        ("cornell", {"RT_TAIL": "0", "RT_FUSE_RAYGEN": "0"}),   # (RT_TAIL=0 above: the first bounce makes its camera rays itself; here k_raygen does)
+        ("globe", {"RT_TAIL": "0"}),
+        ("cornell", {"RT_TAIL": "0", "RT_PIXEL_BLOCKS": "2"}),  # ... in the pixels-by-samples order of the queue
+        ("blue_ball", {"RT_TAIL": "0", "RT_FUSE": "1"}),        # a sweep that is not lean, fused: k_bounce<16, WALK_SWEEP, .., FIRST>
         ("knight", {"RT_GPU_BUILD": "1"}),                     # the mesh's four-wide tree from the GPU builder (Morton order, radix tree, fold)
         ("knight", {"RT_GPU_BUILD": "1", "RT_COOP": "32"}),
         ("knight", {"RT_GPU_BUILD": "1", "RT_ORDERED": "0", "RT_FEATURES": "all"}),
