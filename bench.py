@@ -113,7 +113,7 @@ class MergedStats:
     the same time, so the stage times add up to more than the step takes)."""
 
     def __init__(self, parts):
-        for f in ("rays", "paths", "rays_tail", "paths_tail", "ms_extend", "ms_shade", "ms_tail", "extend_launches", "shade_launches", "tail_launches"):
+        for f in ("rays", "paths", "rays_tail", "paths_tail", "paths_first", "ms_extend", "ms_shade", "ms_tail", "extend_launches", "shade_launches", "tail_launches"):
             setattr(self, f, sum(getattr(p, f) for p in parts))
         self.ms_total = max(p.ms_total for p in parts)
         self.extend_kernel = parts[-1].extend_kernel
@@ -323,7 +323,8 @@ def run_workload(args, scene_name, steps, warmup, torch, rt, parallel, dist, ran
     sample_bytes = 3 * elem
     survivors = (rays_nontail - paths) + paths_tail if not fused else rays_step - paths   # queue entries written by shade / bounce launches
     compulsory = {
-        "k_bounce": path_bytes * rays_step + path_bytes * survivors + sample_bytes * paths + scene_bytes * n_extend,
+        # (the first bounce of a batch on a sweep scene makes its camera rays itself: those queue entries are never read)
+        "k_bounce": path_bytes * (rays_step - float(last.paths_first)) + path_bytes * survivors + sample_bytes * paths + scene_bytes * n_extend,
         "k_extend": (ray_bytes + hit_bytes) * rays_nontail + scene_bytes * n_extend,
         "k_extend_refill": (ray_bytes + hit_bytes) * rays_nontail + scene_bytes * n_extend,
         "k_shade": (path_bytes + hit_bytes) * rays_nontail + path_bytes * survivors + sample_bytes * (paths - paths_tail),
@@ -422,7 +423,7 @@ def run_workload(args, scene_name, steps, warmup, torch, rt, parallel, dist, ran
                               "launches_ms_sum": ms_launch_sum, "launches_fit_the_step": bool(ms_launch_sum <= float(last.ms_total) * 1.0005),
                               "extend_launches": n_extend, "shade_launches": n_shade, "tail_launches": n_tail,
                               "lanes": 1 if instrumented else None, "timed": bool(instrumented)},
-        "stage_counts": {"rays": int(last.rays), "paths": int(last.paths), "rays_tail": int(last.rays_tail), "paths_tail": int(last.paths_tail),
+        "stage_counts": {"rays": int(last.rays), "paths": int(last.paths), "rays_tail": int(last.rays_tail), "paths_tail": int(last.paths_tail), "paths_first": int(last.paths_first),
                          "extend_kernel": int(last.extend_kernel), "max_depth_reached": int(last.max_depth_reached), "batches": int(last.batches)},
         "scene_setup_ms": {"load_and_flatten": ms_load, "upload_total": up.ms_total, "upload_validate": up.ms_validate,
                            "upload_build_layouts": up.ms_build, "upload_copy": up.ms_copy, "device_bytes": int(up.bytes_device),

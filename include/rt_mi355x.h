@@ -254,7 +254,7 @@ typedef struct rt_stats {
     uint32_t tail_launches;
     uint32_t extend_kernel; /* which kernel ms_extend times: 0 k_extend, 1 k_extend_refill, 2 k_bounce (fused) */
     uint64_t paths_tail;  /* paths that entered tail launches (two-kernel bounces only, like rays_tail) */
-    uint64_t reserved;
+    uint64_t paths_first;  /* paths whose camera rays the first bounce launch made itself (sweep scenes): k_raygen neither wrote nor k_bounce read their queue entries */
 } rt_stats;
 /* ms_extend / ms_shade / ms_tail are filled only while launch timing is on: a HIP event either side of every launch
  * costs the stream about 5 us each (0.7 ms of a 21 ms image), so it is off by default; rays, paths, launch counts

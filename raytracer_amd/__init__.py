@@ -55,7 +55,7 @@ class RtStats(C.Structure):
         ("ms_shade", C.c_double), ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32),
         ("batches", C.c_uint32), ("max_depth_reached", C.c_uint32),
         ("ms_tail", C.c_double), ("rays_tail", C.c_uint64), ("tail_launches", C.c_uint32), ("extend_kernel", C.c_uint32),
-        ("paths_tail", C.c_uint64), ("reserved", C.c_uint64),
+        ("paths_tail", C.c_uint64), ("paths_first", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:

@@ -1120,6 +1120,7 @@ struct Engine : EngineBase {
         size_t ev = 0;
         std::vector<Span> spans;
         uint32_t n_extend = 0, n_shade = 0, n_tail = 0;  // launches (counted whether or not they are timed)
+        uint64_t paths_first = 0;                          // paths of batches whose first bounce made the camera rays
         uint32_t deepest = 0;
     };
     enum StepResult { STEP_PROGRESS, STEP_BLOCKED, STEP_DONE };
@@ -1248,12 +1249,14 @@ struct Engine : EngineBase {
                 L.ring ^= 1u;
                 for (uint32_t k = 0; k < PEEK_SLOTS; k++) L.peek[L.ring * PEEK_SLOTS + k] = PEEK_UNKNOWN;
                 __atomic_thread_fence(__ATOMIC_SEQ_CST);
-                HIP_CHECK(hipMemsetAsync(w.sample_rgb, 0, (size_t)b.n_paths * 3 * sizeof(T), st));
+                // (every path stores its sample exactly once, when it ends, where DScene::emit_once holds: nothing to clear)
+                if (!S.emit_once || max_bounces == 0) HIP_CHECK(hipMemsetAsync(w.sample_rgb, 0, (size_t)b.n_paths * 3 * sizeof(T), st));
                 // Sweep scenes (one fused launch per bounce): the first bounce makes the camera rays itself - 84 B per path
                 // neither written nor read, one launch fewer (cornell 0.65 ms of 19.5, globe of 3.0) - unless the batch is
                 // small enough to start in the tail launch, which reads a queue.
                 b.first_fused = fused && tune.fuse_raygen && max_bounces > 0 && b.n_paths > tail_threshold && S.n_sweep > 0;
                 if (b.first_fused) {
+                    R.paths_first += b.n_paths;
                     // the totals of the (unwritten) dense queue 0, clear the counts of queue 1, rays += n_paths
                     rtd::launch_scan_tiles(nullptr, b.n_tiles, w.tile_offsets, w.tile_counts[1], w.counts, w.ray_total, nullptr, st, b.n_paths);
                     return STEP_PROGRESS;
@@ -1389,6 +1392,7 @@ struct Engine : EngineBase {
             stats->extend_launches += R.n_extend;
             stats->shade_launches += R.n_shade;
             stats->tail_launches += R.n_tail;
+            stats->paths_first += R.paths_first;
         }
         stats->extend_kernel = fused ? 2u : refill_lanes() > 0 ? 1u : 0u;
         stats->paths = npix * ns;

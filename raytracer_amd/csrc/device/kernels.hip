@@ -2031,15 +2031,18 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
             thr = coeff(thr, attenuation);
         }
     }
-    if (contributes) {
-        // The sample buffer starts at zero.  Where a path can only add once (DScene::emit_once) the sum is the
-        // addend itself: a plain store, no read of the line (cornell: 11 % of k_bounce's HBM-side reads).
-        T* dst = sample_rgb + (uint64_t)pid * 3;
-        if (S.emit_once) {
-            dst[0] = add.x; dst[1] = add.y; dst[2] = add.z;
-        } else {
-            dst[0] += add.x; dst[1] += add.y; dst[2] += add.z;
+    // Where a path can only add once, when it ends (DScene::emit_once: every scene without a light inside a checker),
+    // its sample is the addend itself - or zero if it ends in the dark: ONE plain store per path, at its end, no read of
+    // the line (cornell: 11 % of k_bounce's HBM-side reads) and no clearing of the sample buffer beforehand (24 B per
+    // path and a launch per batch: the host skips its memset for such scenes).  Otherwise the buffer starts at zero.
+    if (S.emit_once) {
+        if (!alive) {
+            T* dst = sample_rgb + (uint64_t)pid * 3;
+            dst[0] = add.x; dst[1] = add.y; dst[2] = add.z;  // (add is zero unless the path saw a light or the sky)
         }
+    } else if (contributes) {
+        T* dst = sample_rgb + (uint64_t)pid * 3;
+        dst[0] += add.x; dst[1] += add.y; dst[2] += add.z;
     }
     return alive;
 }

@@ -225,6 +225,7 @@ void add_stats(rt_stats* total, const rt_stats& part, bool same_device) {
     total->tail_launches += part.tail_launches;
     total->rays_tail += part.rays_tail;
     total->paths_tail += part.paths_tail;
+    total->paths_first += part.paths_first;
     total->batches += part.batches;
     total->extend_kernel = part.extend_kernel;
     total->max_depth_reached = std::max(total->max_depth_reached, part.max_depth_reached);

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(rt):
 def test_struct_layouts(rt, orc):
     assert rt.RAY_DTYPE.itemsize == 72      # rt_ray: 9 doubles
     assert rt.HIT_DTYPE.itemsize == 112     # rt_hit: 6 int32 + 9 doubles + second_t, inst_id, pad
-    assert C.sizeof(rt.RtStats) == 96      # 56 + ms_tail, rays_tail, tail_launches, extend_kernel, paths_tail, reserved
+    assert C.sizeof(rt.RtStats) == 96      # 56 + ms_tail, rays_tail, tail_launches, extend_kernel, paths_tail, paths_first
     assert orc.HIT_DTYPE.itemsize == 96 + 16
 
 
