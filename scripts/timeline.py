@@ -11,13 +11,13 @@ from collections import defaultdict
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 limit = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# the last step begins at the last k_raygen that follows a k_quantize (or the first raygen)
-starts = [i for i, r in enumerate(rows) if "k_raygen" in r["Kernel_Name"] and (i == 0 or "k_raygen" not in rows[i - 1]["Kernel_Name"])]
+# the last step ends at the last k_quantize and begins after the k_quantize before it (or at the first kernel)
 ends = [i for i, r in enumerate(rows) if "k_quantize" in r["Kernel_Name"]]
 last_end = ends[-1] if ends else len(rows) - 1
-first = max(i for i in starts if i < last_end)
-while first > 0 and ("hipMemset" in rows[first - 1]["Kernel_Name"] or "fill" in rows[first - 1]["Kernel_Name"].lower()):
-    first -= 1
+first = ends[-2] + 1 if len(ends) > 1 else 0
+# (skip what the harness runs between two steps: torch's fills and copies up to the first kernel of the library)
+while first < last_end and "rtd::" not in rows[first]["Kernel_Name"] and "fill" not in rows[first]["Kernel_Name"].lower():
+    first += 1
 sel = rows[first:last_end + 1]
 t0 = int(sel[0]["Start_Timestamp"])
 prev_end = t0
