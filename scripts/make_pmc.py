@@ -12,14 +12,16 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 SCENES = ("cornell", "knight", "blocks_ball", "globe", "two_spheres", "blue_ball")
 
 
 def kernel_of(name: str):
-    if "k_bounce" in name:
-        return "k_bounce_tail" if ("Lb1EE" in name or ", true>" in name) else "k_bounce"
+    if "k_bounce" in name:  # k_bounce<T, STACK, MODE, CAN_TAIL, FIRST>: the tail launch is the CAN_TAIL = true instantiation
+        m = re.search(r"k_bounce<[^,]+, *\d+, *\d+, *(true|false)", name) or re.search(r"k_bounceI\w+?Li\d+ELi\d+ELb([01])E", name)
+        return "k_bounce_tail" if m and m.group(1) in ("true", "1") else "k_bounce"
     for k in ("k_extend_refill", "k_extend", "k_shade", "k_raygen", "k_accumulate", "k_scan_tiles", "k_quantize"):
         if k in name:
             return k

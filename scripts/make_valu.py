@@ -5,6 +5,9 @@ VALU wave-instructions per ray of the dominant kernel = SQ_INSTS_VALU summed ove
 rays per step minus the tail launch's).  bench.py multiplies it by the rays of a launch and divides by the launch's
 duration, measured live, to price the kernel against the VALU issue rate (1024 SIMDs x 2.4 GHz / 4 cycles)."""
 import collections
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from make_pmc import kernel_of  # noqa: E402
 import csv
 import glob
 import json
@@ -22,9 +25,8 @@ for scene in ("cornell", "knight", "blocks_ball"):
     n = collections.Counter()
     for r in csv.DictReader(open(files[0])):
         k = r["Kernel_Name"]
-        tail = "Lb1EE" in k or ", true>" in k
-        name = ("k_bounce_tail" if tail else "k_bounce") if "k_bounce" in k else "k_extend_refill" if "k_extend_refill" in k else "k_extend" if "k_extend" in k else "k_shade" if "k_shade" in k else None
-        if name:
+        name = kernel_of(k)  # (scripts/make_pmc.py: the tail launch is k_bounce's CAN_TAIL = true instantiation)
+        if name in ("k_bounce", "k_bounce_tail", "k_extend_refill", "k_extend", "k_shade"):
             agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] == "SQ_INSTS_VALU":
                 n[name] += 1

@@ -536,6 +536,76 @@ def test_every_object_kind_against_the_oracle(rt, orc, tmp_path, monkeypatch, wi
                         noise=lambda: o.render(W, H, 0, H, 8, 20, seed=5, threads=8)[1])
 
 
+def _mesh_scene(obj_path):
+    return """{
+      camera: {lookFrom: [0.3,2.5,-7], lookAt: [0,0.6,0], directionUp: [0,1,0], fieldOfView: 40, aspectRatio: [1,1],
+               aperture: 0, distanceToFocus: 7, startTime: 0, endTime: 1},
+      background: {type: "gradient", direction: [0,1,0], colour0: [1,1,1], colour1: [0.4,0.6,1.0]},
+      textures: {r: {type: "solidColour", colour: [0.8,0.3,0.2]}},
+      materials: {red: {type: "lambertian", texture: "r"}},
+      objects: {shape: {type: "mesh", filename: "%s", material: "red"},
+                turned: {type: "rotateY", prototype: "shape", degrees: 20},
+                dot: {type: "sphere", centre: [2.2,0.4,0.5], radius: 0.4, material: "red"}},
+      world: ["turned", "dot"],
+    }""" % obj_path  # (two objects: a world of one has no world tree, and then no four-wide trees at all)
+
+
+@pytest.mark.parametrize("kind", ["one", "two", "duplicates", "sliver_grid", "far_apart"])
+def test_gpu_built_trees_of_awkward_meshes(rt, tmp_path, monkeypatch, kind):
+    # The GPU builder (csrc/device/bvh_build.hip) on meshes that stress its corners: a single leaf (super-root only), two
+    # leaves, many identical triangles (equal Morton codes: the radix tree falls back on the leaves' positions), a grid of
+    # slivers whose centroids lie on a line, two clusters a long way apart (most of the code's bits unused).  The tree only
+    # culls: hit records and images must equal the host-built tree's bit for bit.
+    rng = np.random.default_rng(3)
+    verts, faces = [], []
+
+    def tri(a, b, c):
+        verts.extend([a, b, c])
+        n = len(verts)
+        faces.append((n - 2, n - 1, n))
+
+    if kind == "one":
+        tri((-1, 0, 0), (1, 0, 0), (0, 1.5, 0.2))
+    elif kind == "two":
+        tri((-1, 0, 0), (1, 0, 0), (0, 1.5, 0.2))
+        tri((-1, 0, 0.5), (0, 1.5, 0.7), (1, 0, 0.5))
+    elif kind == "duplicates":
+        for _ in range(37):
+            tri((-1, 0, 0), (1, 0, 0), (0, 1.5, 0.2))
+        tri((-1.2, 0.1, 0.4), (0.9, 0.2, 0.5), (0.1, 1.2, 0.6))
+    elif kind == "sliver_grid":
+        for k in range(300):
+            x = -1.5 + 0.01 * k
+            tri((x, 0, 0.001 * k), (x + 0.009, 0, 0.001 * k), (x, 1.2, 0.001 * k))
+    else:
+        for centre in ((-1.0, 0.5, 0.0), (900.0, 0.5, 4000.0)):
+            for _ in range(64):
+                p = np.array(centre) + rng.uniform(-0.4, 0.4, 3)
+                tri(tuple(p), tuple(p + rng.uniform(-0.3, 0.3, 3)), tuple(p + rng.uniform(-0.3, 0.3, 3)))
+    obj = tmp_path / "awkward.obj"
+    with open(obj, "w") as f:
+        for v in verts:
+            f.write("v %.9g %.9g %.9g\n" % v)
+        for a, b, c in faces:
+            f.write("f %d %d %d\n" % (a, b, c))
+    scene = rt.Scene.from_text(_mesh_scene(str(obj)))
+    host = rt.Renderer(0)
+    host.upload(scene)
+    monkeypatch.setenv("RT_GPU_BUILD", "1")
+    gpu = rt.Renderer(0)
+    gpu.upload(scene)
+    assert host.upload_stats().gpu_built_trees == 0 and gpu.upload_stats().gpu_built_trees == 1
+    W = 64
+    H = scene.image_height(W)
+    rays = host.primary_rays(W, H, 0, H, 0, seed=9)
+    a, b = host.trace(rays, seed=2), gpu.trace(rays, seed=2)
+    for field in ("hit", "owner", "sub", "front_face", "material", "t", "p", "n", "u", "v", "second_t"):
+        assert np.array_equal(a[field], b[field]), field
+    assert a["hit"].sum() > 0
+    ra, rb = host.render_rows(W, H, 0, H, 4, 8, seed=1), gpu.render_rows(W, H, 0, H, 4, 8, seed=1)
+    assert np.array_equal(ra[1], rb[1]) and ra[2].rays == rb[2].rays
+
+
 @pytest.mark.parametrize("name", ["knight", "blocks_ball", "blue_ball"])
 def test_rays_that_start_far_outside_the_scene(gpu_scenes, oracle_scenes, name):
     # A path scattered off the unbounded Plane can start thousands of scene sizes away.  The f32 box tests of the tree
