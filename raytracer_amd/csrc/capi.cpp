@@ -569,7 +569,13 @@ struct Engine : EngineBase {
             } free_trees{gpu_trees};
             const long gpu_build_min = tune.gpu_build >= 0 ? tune.gpu_build : RT_GPU_BUILD_DEFAULT_MIN;
             const clock::time_point t_gpu = clock::now();
-            if (tune.bvh4 && d.tlas_root >= 0 && gpu_build_min > 0) {
+            // (a world of one boxed object has no world tree - BVHNode::from_vec makes a plain list of it, src/hitting.rs:165-170 -
+            // but a mesh in it is walked through its four-wide tree all the same)
+            bool any_mesh = false;
+            for (uint64_t i = 0; i < d.n_objects; i++)
+                if (d.objects[i].kind == RT_OBJ_BLAS) any_mesh = true;
+            const bool want4 = tune.bvh4 && (d.tlas_root >= 0 || any_mesh);
+            if (want4 && gpu_build_min > 0) {
                 std::vector<char> tried(d.n_nodes, 0);
                 for (uint64_t i = 0; i < d.n_objects; i++) {
                     if (d.objects[i].kind != RT_OBJ_BLAS || tried[(size_t)d.objects[i].first]) continue;
@@ -600,7 +606,7 @@ struct Engine : EngineBase {
                 return nullptr;
             };
             for (int use_sah = tune.sah == 0 ? 0 : 1; use_sah >= 0; use_sah--) {
-                if (!tune.bvh4 || d.tlas_root < 0) break;
+                if (!want4) break;
                 std::vector<rtd::WideNode4> v;
                 int need = 0, need_world = 0;
                 auto build = [&](int32_t root, int* need_out) {
@@ -612,7 +618,7 @@ struct Engine : EngineBase {
                 {
                     const int meshes_too = use_sah;
                     if (tune.sah == 2) use_sah = 0;  // RT_SAH=2: meshes only
-                    S.tlas_root4 = build(d.tlas_root, &need_world);
+                    S.tlas_root4 = d.tlas_root >= 0 ? build(d.tlas_root, &need_world) : -1;
                     use_sah = meshes_too;
                 }
                 for (uint64_t i = 0; i < d.n_objects; i++)
@@ -629,7 +635,7 @@ struct Engine : EngineBase {
                 stack_need4 = need + need_world + 3;
                 std::vector<rtd::DNode4> packed;
                 if (stack_need4 <= lds_part + RT_STACK_OVERFLOW && quantize_nodes4(v, packed)) {
-                    if (tune.debug && v[(size_t)S.tlas_root4].child[0] >= 0) {
+                    if (tune.debug && S.tlas_root4 >= 0 && v[(size_t)S.tlas_root4].child[0] >= 0) {
                         const rtd::WideNode4& w = v[(size_t)v[(size_t)S.tlas_root4].child[0]];
                         for (int k = 0; k < 4; k++)
                             std::fprintf(stderr, "  world slot %d: child %d  [%g %g %g] - [%g %g %g]\n", k, w.child[k], w.lo[0][k], w.lo[1][k],
@@ -849,6 +855,32 @@ struct Engine : EngineBase {
                 S.far_origin = far_origin_limit(d);
             }
         }
+        if (d.tlas_root < 0) {
+            // No world tree (at most one boxed object, src/hitting.rs:165-170): the only f32 box tests are those of that
+            // object's mesh tree, in ITS space.  Its transform is rigid, so the sphere around the mesh's root box, moved to
+            // world space, bounds what far_shift has to bring a far ray near to.
+            for (uint64_t e = 0; e < d.n_top; e++) {
+                const int32_t oi = d.top_list[e];
+                if (oi < 0 || d.objects[oi].kind != RT_OBJ_BLAS) continue;
+                const rt_node& root = d.nodes[d.objects[oi].first];
+                double c[3], r2 = 0;
+                bool finite = true;
+                for (int k = 0; k < 3; k++) {
+                    if (!std::isfinite(root.lo[k]) || !std::isfinite(root.hi[k])) finite = false;
+                    c[k] = 0.5 * (root.lo[k] + root.hi[k]);
+                    r2 += 0.25 * (root.hi[k] - root.lo[k]) * (root.hi[k] - root.lo[k]);
+                }
+                if (!finite) continue;
+                if (d.objects[oi].xform >= 0) {  // p' = m p + b  ->  p = m^T (p' - b)
+                    const rt_xform& X = d.xforms[d.objects[oi].xform];
+                    const double q[3] = {c[0] - X.b[0], c[1] - X.b[1], c[2] - X.b[2]};
+                    for (int k = 0; k < 3; k++) c[k] = X.m[k] * q[0] + X.m[3 + k] * q[1] + X.m[6 + k] * q[2];
+                }
+                for (int k = 0; k < 3; k++) S.bound_centre[k] = (T)c[k];
+                S.bound_radius = (T)(std::sqrt(r2) * 1.001 + 1e-3 * scene_scale(d));
+                S.far_origin = far_origin_limit(d);
+            }
+        }
         // RT_ORDERED=0 (environment) walks trees in the reference's fixed left-first order (A/B runs).
         S.ordered = tune.ordered ? 1 : 0;
         // RT_COOP=0: the tail launch walks meshes with one lane per path throughout (A/B runs; the image is the same).
@@ -1010,7 +1042,7 @@ struct Engine : EngineBase {
     // while others of their wave still walk, as soon as n lanes wait (measured: slower).
     int refill_lanes() const {
         int refill = 0;
-        if (S.nodes4 && S.n_sweep == 0 && !small.blob) {
+        if (S.nodes4 && S.tlas_root4 >= 0 && S.n_sweep == 0 && !small.blob) {  // (Walk4 starts at the world tree's root)
             refill = S.has_meshes ? 0 : 64;
             if (tune.refill >= 0) refill = tune.refill;
         }

@@ -16,7 +16,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, SCENES, assert_image_parity
+from conftest import GOLDEN, ROOT, SCENES, assert_image_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -533,6 +533,54 @@ def test_every_object_kind_against_the_oracle(rt, orc, tmp_path, monkeypatch, wi
     rgb8, sums, st = r.render_rows(W, H, 0, H, 8, 20, seed=4)
     o8, osums, orays = o.render(W, H, 0, H, 8, 20, seed=4, threads=8)
     assert_image_parity(sums, osums, st.rays, orays, 8, 20, label="every object kind",
+                        noise=lambda: o.render(W, H, 0, H, 8, 20, seed=5, threads=8)[1])
+
+
+def test_a_world_of_one_mesh(rt, orc, gpu_scenes):
+    # One boxed object in the world: BVHNode::from_vec makes a plain list of it, no world tree (src/hitting.rs:165-170) - the
+    # knight alone on its board.  The mesh must still be walked through its four-wide tree (round 3: it fell back to the
+    # binary walk), and rays scattered far along the unbounded board must still be brought near for the f32 box tests
+    # (the bounding sphere comes from the mesh's root box then, not from a world tree).
+    gpu_scenes("knight")  # (makes sure examples/knight.obj exists)
+    import re
+    text = open(os.path.join(ROOT, "examples", "knight.json5")).read()
+    text, n = re.subn(r"world:\s*\[[^\]]*\]", 'world: ["board", "knight"]', text)
+    assert n == 1
+    scene = rt.Scene.from_text(text, ROOT)
+    o = orc.OracleScene.from_text(text, ROOT)
+    r = rt.Renderer(0)
+    r.upload(scene)
+    assert r.upload_stats().n_nodes4 > 1000
+    W = 64
+    H = scene.image_height(W)
+    prim = o.primary_rays(W, H, 0, H, 0, 11)
+    ph = o.trace(prim, 11)
+    check_hits(r.trace(prim, 11), ph, ph["second_t"])
+    on_mesh = (ph["hit"] == 1) & (ph["sub"] > 0)  # (a triangle of the mesh: its index within the mesh is the part)
+    targets = ph["p"][ph["hit"] == 1]
+    rng = np.random.default_rng(6)
+    parts = []
+    for dist in [1e3, 1e5, 1e7]:
+        n_t = len(targets)
+        d = rng.normal(size=(n_t, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.zeros(n_t, dtype=prim.dtype)
+        rays["o"] = targets + rng.normal(scale=1e-3, size=(n_t, 3)) - d * dist
+        rays["d"] = d
+        rays["time"] = rng.uniform(0, 1, n_t)
+        rays["tmin"] = 0.001
+        rays["tmax"] = np.inf
+        parts.append(rays)
+    far = np.concatenate(parts)
+    want, got = o.trace(far, 9), r.trace(far, 9)
+    assert np.array_equal(got["hit"], want["hit"])
+    hit = want["hit"] == 1
+    tie = np.abs(want["second_t"] - want["t"]) <= 1e-9 * np.abs(want["t"])
+    same = (got["owner"] == want["owner"]) & (got["sub"] == want["sub"])
+    assert np.all(same[hit & ~tie]) and on_mesh.any()
+    rgb8, sums, st = r.render_rows(W, H, 0, H, 8, 20, seed=4)
+    o8, osums, orays = o.render(W, H, 0, H, 8, 20, seed=4, threads=8)
+    assert_image_parity(sums, osums, st.rays, orays, 8, 20, label="one mesh",
                         noise=lambda: o.render(W, H, 0, H, 8, 20, seed=5, threads=8)[1])
 
 
