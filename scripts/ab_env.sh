@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage: scripts/ab_env.sh "<bench args>" "VAR=a" "VAR=b" ...   (one bench run per environment setting)
+# usage (on the GPU box): scripts/ab_env.sh "<bench args>" "VAR=a" "VAR=b VAR2=c" ...   one bench line per environment setting
 args="$1"; shift
 for setting in "$@"; do
-  echo "== $setting $args"
-  env $setting timeout -k 10 120 python bench.py --no-cpu-baseline $args | python -c "import json,sys; d=json.load(sys.stdin); print(round(d['value'],1), round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['stage_ms_last_step'].items()})" || exit 1
+  env $setting timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-extra $args > /tmp/ab_line.json 2>/tmp/ab_line.err || { tail -5 /tmp/ab_line.err; exit 1; }
+  python3 -c "import json,sys; d=json.load(open('/tmp/ab_line.json')); print('$setting', '$args', round(d['value'],1), round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['stage_ms_last_step'].items() if k in ('extend','shade','tail')})"
 done
