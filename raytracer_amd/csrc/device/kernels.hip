@@ -17,6 +17,7 @@
 //
 // The file is compiled once per RT_PART (0-5: extend / bounce / the rest, for double and for float; Makefile)
 // so that the six groups of kernel instantiations build in parallel; without RT_PART everything is one unit.
+#include <type_traits>
 #include "rt_device.h"
 
 #include "../../../include/rt_mi355x.h"
@@ -142,6 +143,87 @@ template <typename T> __device__ V3<T> random_in_unit_disc(Rng<T>& rng) {  // sr
         V3<T> p = mk(px, py, (T)0.0);
         if (length_squared(p) <= (T)1.0) return p;
     }
+}
+
+// Try number `tr` of random_in_unit_sphere on the stream (key, pixel, sample, bounce) taken from its start: the
+// stream's numbers 3 tr, 3 tr + 1, 3 tr + 2 (number i is half i & 1 of block i >> 1), each through range(-1, 1).
+template <typename T>
+__device__ __forceinline__ V3<T> unit_sphere_try(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t bounce,
+                                                 uint32_t tr, bool* inside) {
+    const uint32_t first = 3u * tr, block = first >> 1;
+    uint32_t a[4], b[4];
+    philox4x32_10(pixel, sample, bounce, block, k0, k1, a);
+    philox4x32_10(pixel, sample, bounce, block + 1u, k0, k1, b);
+    const uint64_t a0 = (uint64_t)a[0] | ((uint64_t)a[1] << 32), a1 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+    const uint64_t b0 = (uint64_t)b[0] | ((uint64_t)b[1] << 32), b1 = (uint64_t)b[2] | ((uint64_t)b[3] << 32);
+    const bool odd = (first & 1u) != 0;
+    const T u0 = bits_to_unit<T>(odd ? a1 : a0), u1 = bits_to_unit<T>(odd ? b0 : a1), u2 = bits_to_unit<T>(odd ? b1 : b0);
+    const T lo = (T)-1.0, hi = (T)1.0;
+    const V3<T> p = mk(lo + (hi - lo) * u0, lo + (hi - lo) * u1, lo + (hi - lo) * u2);
+    *inside = length_squared(p) <= (T)1.0;
+    return p;
+}
+
+// random_in_unit_sphere for the lanes of a wave that `want` one, each on its own fresh stream (key, pixel, sample,
+// bounce): the same point as the loop above returns - the first try that falls inside - found by the whole wave.
+// A loop per lane runs as long as the unluckiest of 64 lanes (6.4 tries on average where every lane draws, 1.9 are
+// what a lane needs; cornell: 16 % of its k_bounce).  Here every round shares the wave out among the lanes still
+// without a point: R of them get 64 / R lanes each (a power of two), which evaluate that many consecutive tries at
+// once; the first one inside wins.  Tries are independent of each other (counter-based streams), so this is the
+// same arithmetic on the same numbers.  Rounds: ~3.3 on average where every lane draws, 1 for a lone lane.
+// EVERY lane of the wave must call this (want = false for those that need nothing).
+// UNIFORM_BOUNCE: `bounce` is the same in every lane (a launch per bounce).
+template <typename T, bool UNIFORM_BOUNCE>
+__device__ __forceinline__ V3<T> wave_first_in_unit_sphere(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample,
+                                                           uint32_t bounce, bool want) {
+    const int lane = (int)(threadIdx.x & 63u);
+    V3<T> res = mk((T)0.0, (T)0.0, (T)0.0);
+    bool pending = want;
+    uint32_t next_try = 0;  // (wave-uniform: every pending lane has failed the same tries)
+    for (;;) {
+        const uint64_t P = __ballot(pending);
+        if (P == 0) break;
+        const int R = __popcll(P);
+        const int lg = 6 - (32 - __clz(R - 1));  // 64 >> ceil(log2 R) lanes per pending path
+        if (lg == 0) {                           // more than 32 pending: a try each, by themselves
+            if (pending) {
+                bool in;
+                const V3<T> p = unit_sphere_try<T>(k0, k1, pixel, sample, bounce, next_try, &in);
+                if (in) {
+                    res = p;
+                    pending = false;
+                }
+            }
+            next_try += 1u;
+            continue;
+        }
+        const int g = 1 << lg;
+        // slot j (lanes j g .. j g + g - 1) serves the j-th pending lane: a permutation of the lanes that puts the
+        // pending ones first (one push through the LDS crossbar) tells slot j who that is
+        const int below = (int)__popcll(P & ((1ull << lane) - 1ull));
+        const int place = pending ? below : R + (lane - below);
+        const int by_rank = __builtin_amdgcn_ds_permute(place << 2, lane);
+        const int slot = lane >> lg, sub = lane & (g - 1);
+        const bool serve = slot < R;
+        const int owner = __shfl(by_rank, serve ? slot : 0);
+        const uint32_t o_pixel = (uint32_t)__shfl((int)pixel, owner), o_sample = (uint32_t)__shfl((int)sample, owner);
+        const uint32_t o_bounce = UNIFORM_BOUNCE ? bounce : (uint32_t)__shfl((int)bounce, owner);
+        bool in = false;
+        V3<T> p = mk((T)0.0, (T)0.0, (T)0.0);
+        if (serve) p = unit_sphere_try<T>(k0, k1, o_pixel, o_sample, o_bounce, next_try + (uint32_t)sub, &in);
+        const uint64_t A = __ballot(in);
+        // the first try inside among the owner's slot
+        const uint64_t mine = (A >> ((below << lg) & 63)) & (g == 64 ? ~0ull : ((1ull << g) - 1ull));
+        const bool found = pending && mine != 0;
+        const int from = found ? (below << lg) + (__ffsll((long long)mine) - 1) : lane;
+        const V3<T> got = mk(__shfl(p.x, from), __shfl(p.y, from), __shfl(p.z, from));
+        if (found) {
+            res = got;
+            pending = false;
+        }
+        next_try += (uint32_t)g;
+    }
+    return res;
 }
 
 __device__ __forceinline__ void path_ids(const DBatch& B, uint32_t pid, uint32_t* pixel, uint32_t* sample) {
@@ -1923,15 +2005,25 @@ __device__ __forceinline__ int resolve_checkered(const DScene<T>& S, int mi, T u
 // One bounce of cast_ray for one path (src/hitting.rs:11-31) after its closest-hit query: adds what
 // the path sees (light / sky) to its sample, and scatters.  mf = material | front_face << 31, or
 // RT_MISS.  Returns true if the path goes on: nr is the scattered ray, thr the new throughput.
-template <typename T, bool SHARED_DRAW = true>
-__device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, const Ray<T>& ray, V3<T>& thr, uint32_t pid,
-                                           uint32_t mf, T t, V3<T> n, T u, T v, T* sample_rgb, uint32_t depth,
+// EVERY lane of the wave must call this (active = false: no path in this lane): the unit-sphere draw in the middle
+// is made by the wave together (wave_first_in_unit_sphere).  UNIFORM_DEPTH: depth is the same in every lane.
+#ifndef RT_COOP_DRAW
+#define RT_COOP_DRAW 1  // 0: every lane runs its own rejection loop (A/B builds)
+#endif
+template <typename T, bool UNIFORM_DEPTH>
+__device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, bool active, const Ray<T>& ray, V3<T>& thr,
+                                           uint32_t pid, uint32_t mf, T t, V3<T> n, T u, T v, T* sample_rgb, uint32_t depth,
                                            uint32_t max_bounces, Ray<T>& nr) {
     const T PI = (T)3.14159265358979323846264338327950288;
     bool alive = false;
     V3<T> add = mk((T)0.0, (T)0.0, (T)0.0);
     bool contributes = false;
-    if (mf == RT_MISS) {  // sky(ray), src/hitting.rs:29
+    const bool hit = active && mf != RT_MISS;
+    const bool front = (mf & 0x80000000u) != 0;
+    DMaterial<T> m;  // the material that scatters (hit lanes)
+    m.type = -1;
+    uint32_t pixel = 0, sample = 0;
+    if (active && mf == RT_MISS) {  // sky(ray), src/hitting.rs:29
         V3<T> c;
         const DSky<T>& sky = *S.sky;
         if (sky.gradient) {  // src/camera.rs:78-86
@@ -1943,47 +2035,53 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
         }
         add = coeff(thr, c);
         contributes = true;
-    } else {
-        bool front = (mf & 0x80000000u) != 0;
+    }
+    if (hit) {
         int mi = (int)(mf & 0x7fffffffu);
-        V3<T> p = ray.at(t);  // HitRecord::new: intersection = ray.at(distance)
         // emitted(): Checkered picks its part with sin(k u) sin(k v) - no PI (src/materials.rs:175-183)
         {
             int me = mi;
-            DMaterial<T> m = S.materials[me];
+            DMaterial<T> em = S.materials[me];
             // (a checker none of whose parts is a light emits nothing: m.image == 0 then, set at upload,
             // and the two f64 sines are skipped)
-            if (m.type == RT_MAT_CHECKERED && m.image != 0) {
+            if (em.type == RT_MAT_CHECKERED && em.image != 0) {
                 me = resolve_checkered(S, me, u, v, (T)1.0);
-                m = S.materials[me];
+                em = S.materials[me];
             }
-            if (m.type == RT_MAT_DIFFUSE_LIGHT && front) {  // src/materials.rs:129-136
-                add = coeff(thr, texture_value(S, m, u, v));
+            if (em.type == RT_MAT_DIFFUSE_LIGHT && front) {  // src/materials.rs:129-136
+                add = coeff(thr, texture_value(S, em, u, v));
                 contributes = true;
             }
         }
         // scatter(): Checkered picks with sin(k PI u) sin(k PI v) (src/materials.rs:166-174)
-        DMaterial<T> m = S.materials[mi];
+        m = S.materials[mi];
         if (m.type == RT_MAT_CHECKERED) {
             mi = resolve_checkered(S, mi, u, v, PI);
             m = S.materials[mi];
         }
-        uint32_t pixel, sample;
         path_ids(B, pid, &pixel, &sample);
-        Rng<T> rng(B.seed, DOMAIN_MATERIAL, pixel, sample, depth);
+    }
+    // Lambertian, Metal and Isotropic each begin with one random_in_unit_sphere (src/materials.rs:33, 58, 148) on the
+    // bounce's fresh stream and draw nothing after it: drawn here, once, by the wave together.
+    const bool draws = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_METAL || m.type == RT_MAT_ISOTROPIC;
+    V3<T> in_sphere;
+    if constexpr (RT_COOP_DRAW != 0) {
+        in_sphere = wave_first_in_unit_sphere<T, UNIFORM_DEPTH>((uint32_t)B.seed, (uint32_t)(B.seed >> 32) ^ DOMAIN_MATERIAL, pixel,
+                                                                sample, depth, draws);
+    } else {
+        in_sphere = mk((T)0.0, (T)0.0, (T)0.0);
+        if (draws) {
+            Rng<T> rng(B.seed, DOMAIN_MATERIAL, pixel, sample, depth);
+            in_sphere = random_in_unit_sphere(rng);
+        }
+    }
+    if (hit) {
+        V3<T> p = ray.at(t);  // HitRecord::new: intersection = ray.at(distance)
         V3<T> attenuation = mk((T)1.0, (T)1.0, (T)1.0);
         V3<T> dir = n;
         bool scattered = false, metal = false;
-        // Lambertian, Metal and Isotropic each begin with one random_in_unit_sphere (src/materials.rs:33, 58,
-        // 148): drawn here, once, so that the lanes of a wave with mixed materials run the rejection loop
-        // (the dearest part of the shading) together instead of once per material.  (SHARED_DRAW = false:
-        // drawn inside each case - 1 % faster where nearly every hit is Lambertian, the lean sweep's k_bounce.)
-        V3<T> in_sphere = mk((T)0.0, (T)0.0, (T)0.0);
-        if (SHARED_DRAW && (m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_METAL || m.type == RT_MAT_ISOTROPIC))
-            in_sphere = random_in_unit_sphere(rng);
         switch (m.type) {
             case RT_MAT_LAMBERTIAN: {  // src/materials.rs:27-42
-                if (!SHARED_DRAW) in_sphere = random_in_unit_sphere(rng);
                 dir = n + unit_vector(in_sphere);
                 if (near_zero(dir)) dir = n;
                 attenuation = texture_value(S, m, u, v);
@@ -1992,7 +2090,6 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
             }
             case RT_MAT_METAL: {  // :53-66
                 V3<T> reflected = reflect(unit_vector(ray.d), n);
-                if (!SHARED_DRAW) in_sphere = random_in_unit_sphere(rng);
                 dir = reflected + m.param * in_sphere;
                 attenuation = ld3(m.colour);
                 metal = true;
@@ -2005,6 +2102,7 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
                 T cos_theta = fmin(dot(-ud, n), (T)1.0);
                 T sin_theta = sqrt((T)1.0 - cos_theta * cos_theta);
                 bool cannot_refract = ratio * sin_theta > (T)1.0;
+                Rng<T> rng(B.seed, DOMAIN_MATERIAL, pixel, sample, depth);
                 T random_fraction = rng.range((T)0.0, (T)1.0);
                 dir = (cannot_refract || reflectance(cos_theta, ratio) > random_fraction) ? reflect(ud, n)
                                                                                          : refract(ud, n, ratio);
@@ -2012,7 +2110,6 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
                 break;
             }
             case RT_MAT_ISOTROPIC: {  // :146-153
-                if (!SHARED_DRAW) in_sphere = random_in_unit_sphere(rng);
                 dir = in_sphere;
                 attenuation = texture_value(S, m, u, v);
                 scattered = true;
@@ -2035,14 +2132,16 @@ __device__ __forceinline__ bool shade_path(const DScene<T>& S, const DBatch& B, 
     // its sample is the addend itself - or zero if it ends in the dark: ONE plain store per path, at its end, no read of
     // the line (cornell: 11 % of k_bounce's HBM-side reads) and no clearing of the sample buffer beforehand (24 B per
     // path and a launch per batch: the host skips its memset for such scenes).  Otherwise the buffer starts at zero.
-    if (S.emit_once) {
-        if (!alive) {
+    if (active) {
+        if (S.emit_once) {
+            if (!alive) {
+                T* dst = sample_rgb + (uint64_t)pid * 3;
+                dst[0] = add.x; dst[1] = add.y; dst[2] = add.z;  // (add is zero unless the path saw a light or the sky)
+            }
+        } else if (contributes) {
             T* dst = sample_rgb + (uint64_t)pid * 3;
-            dst[0] = add.x; dst[1] = add.y; dst[2] = add.z;  // (add is zero unless the path saw a light or the sky)
+            dst[0] += add.x; dst[1] += add.y; dst[2] += add.z;
         }
-    } else if (contributes) {
-        T* dst = sample_rgb + (uint64_t)pid * 3;
-        dst[0] += add.x; dst[1] += add.y; dst[2] += add.z;
     }
     return alive;
 }
@@ -2094,13 +2193,17 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DScene<T> S, DB
         Ray<T> nr;
         V3<T> thr;
         uint32_t pid = 0;
+        Ray<T> ray;
+        ray.o = ray.d = thr = mk((T)0.0, (T)0.0, (T)0.0);
+        ray.time = (T)0.0;
+        uint32_t mf = RT_MISS;
+        T t = 0, u = 0, v = 0;
+        V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
         if (valid) {
-            Ray<T> ray = load_ray(qin, i);
+            ray = load_ray(qin, i);
             pid = qin.pid[i];
             thr = mk(qin.tr()[i], qin.tg()[i], qin.tb()[i]);
-            uint32_t mf = h.mat_front[i];
-            T t = 0, u = 0, v = 0;
-            V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
+            mf = h.mat_front[i];
             if (mf != RT_MISS) {
                 t = h.t()[i];
                 if (S.needs_uv) {
@@ -2108,8 +2211,8 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DScene<T> S, DB
                 }
                 n = mk(h.nx()[i], h.ny()[i], h.nz()[i]);
             }
-            alive = shade_path(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
         }
+        alive = shade_path<T, true>(S, B, valid, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
         compact_store(alive, tile, nr, thr, pid, qout, tile_counts_out);
     }
 }
@@ -2145,24 +2248,27 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
     // One bounce of one path: the closest-hit query, the hit record, the shading.
     // (known != nullptr: the closest-hit query has been answered already, by the lane's group)
     struct Answer { bool hit; T t; Winner w; };
-    auto bounce_once = [&](const Ray<T>& ray, V3<T>& thr, uint32_t pid, uint32_t depth, Ray<T>& nr, const Answer* known = nullptr) -> bool {
-        const PathRef path = path_of(B, pid);
+    // (called by EVERY lane of the wave, active or not: the shading's draw is the wave's common work, shade_path)
+    auto bounce_once = [&](bool active, const Ray<T>& ray, V3<T>& thr, uint32_t pid, uint32_t depth, Ray<T>& nr, const Answer* known, auto uniform_depth) -> bool {
         T t = 0, u = 0, v = 0;
         V3<T> n = mk((T)0.0, (T)0.0, (T)0.0);
         uint32_t mf = RT_MISS;
-        Winner w;
-        bool hit;
-        if (known) {
-            hit = known->hit; t = known->t; w = known->w;
-        } else {
-            hit = closest_hit<T, MODE>(W, ray, (T)0.001, Lim<T>::inf(), st, path, depth, &t, &w);  // src/hitting.rs:20-21
+        if (active) {
+            const PathRef path = path_of(B, pid);
+            Winner w;
+            bool hit;
+            if (known) {
+                hit = known->hit; t = known->t; w = known->w;
+            } else {
+                hit = closest_hit<T, MODE>(W, ray, (T)0.001, Lim<T>::inf(), st, path, depth, &t, &w);  // src/hitting.rs:20-21
+            }
+            if (hit) {
+                const Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(W, ray, t, w, S.needs_uv != 0);
+                n = sf.normal; u = sf.u; v = sf.v;
+                mf = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
+            }
         }
-        if (hit) {
-            const Surface<T> sf = make_surface<T, WalkFeat<MODE>::value>(W, ray, t, w, S.needs_uv != 0);
-            n = sf.normal; u = sf.u; v = sf.v;
-            mf = (uint32_t)sf.material | (sf.front_face ? 0x80000000u : 0u);
-        }
-        return shade_path<T, MODE != WALK_SWEEP_LEAN>(S, B, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
+        return shade_path<T, decltype(uniform_depth)::value>(S, B, active, ray, thr, pid, mf, t, n, u, v, sample_rgb, depth, max_bounces, nr);
     };
     if (!run_tail) {
         for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < total; base += gridDim.x * BLOCK) {
@@ -2173,22 +2279,24 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
             Ray<T> nr;
             V3<T> thr;
             uint32_t pid = 0;
+            Ray<T> ray;
+            ray.o = ray.d = thr = mk((T)0.0, (T)0.0, (T)0.0);
+            ray.time = (T)0.0;
             if constexpr (FIRST) {
                 tile = d / TILE;
                 if (valid) {
-                    const Ray<T> ray = primary_ray(S, B, d, total, &pid);
+                    ray = primary_ray(S, B, d, total, &pid);
                     thr = mk((T)1.0, (T)1.0, (T)1.0);
-                    alive = bounce_once(ray, thr, pid, depth0, nr);
                 }
             } else {
                 const uint32_t i = valid ? slot_of(tile_offsets, n_tiles, d, base, &tile) : 0u;
                 if (valid) {
-                    const Ray<T> ray = load_ray(qin, i);
+                    ray = load_ray(qin, i);
                     pid = qin.pid[i];
                     thr = mk(qin.tr()[i], qin.tg()[i], qin.tb()[i]);
-                    alive = bounce_once(ray, thr, pid, depth0, nr);
                 }
             }
+            alive = bounce_once(valid, ray, thr, pid, depth0, nr, nullptr, std::true_type{});
             compact_store(alive, tile, nr, thr, pid, qout, tile_counts_out);
         }
         return;
@@ -2278,13 +2386,18 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
                     grouped = true;
                 }
             }
-            if (alive) {
-                Ray<T> nr;
-                if (depth > depth0) extra_queries++;
-                deepest = max(deepest, depth + 1);
-                alive = bounce_once(ray, thr, pid, depth, nr, grouped ? &ans : nullptr);
-                ray = nr;  // the scattered ray is the next bounce's query
-                depth++;
+            {
+                const bool was_alive = alive;
+                Ray<T> nr = ray;
+                if (was_alive) {
+                    if (depth > depth0) extra_queries++;
+                    deepest = max(deepest, depth + 1);
+                }
+                alive = bounce_once(was_alive, ray, thr, pid, depth, nr, grouped ? &ans : nullptr, std::false_type{});
+                if (was_alive) {
+                    ray = nr;  // the scattered ray is the next bounce's query
+                    depth++;
+                }
             }
             RT_TAIL_ITER_END;
         }
