@@ -383,6 +383,8 @@ struct Tuning {
     int coop = 16;              // RT_COOP=n: lane groups answer a tail wave's queries while it has at most n live paths (0: never)
     bool all_features = false;  // RT_FEATURES=all: the general four-wide kernel whatever the scene holds
     long sweep_max = 12;        // RT_SWEEP_MAX: largest world (leaves) that is swept instead of walked
+    int leaf_frac = 8;          // RT_LEAF_FRAC=d: the wave runs its exact triangle tests when d sixteenths of the lanes still in the mesh walk hold a leaf (0: RT_LEAF_VOTE alone)
+    int leaf_vote = 64;         // RT_LEAF_VOTE=n: ... or n lanes do (1: every leaf is tested at once)
     int refill = -1;            // RT_REFILL=n: k_extend_refill's threshold (-1: by scene)
     size_t grid_mult = 0;       // RT_GRID_MULT: persistent blocks per CU (0: 32, or 8 per lane while two lanes run)
     int tail_blocks = 0;        // RT_TAIL_BLOCKS: resident blocks per CU of the tail launch (0: by kind of walk)
@@ -413,6 +415,8 @@ struct Tuning {
         t.all_features = is("RT_FEATURES", 'a');
         t.sweep_max = num("RT_SWEEP_MAX", 12);
         t.refill = (int)num("RT_REFILL", -1);
+        t.leaf_vote = (int)std::max(1l, std::min(64l, num("RT_LEAF_VOTE", 64)));
+        t.leaf_frac = (int)std::max(0l, std::min(16l, num("RT_LEAF_FRAC", 8)));
         const long gm = num("RT_GRID_MULT", 0);
         t.grid_mult = gm > 0 && gm <= 65536 ? (size_t)gm : 0;
         t.tail_blocks = (int)num("RT_TAIL_BLOCKS", 0);
@@ -886,6 +890,8 @@ struct Engine : EngineBase {
         // RT_COOP=0: the tail launch walks meshes with one lane per path throughout (A/B runs; the image is the same).
         // RT_COOP=n: groups of lanes answer a query in the tail launch while a wave has at most n live paths (0: never).
         S.coop = tune.coop;
+        S.leaf_vote = tune.leaf_vote;
+        S.leaf_frac = tune.leaf_frac;
         S.coop_reserve = stack_need4;
         S.has_meshes = S.has_media = 0;
         for (uint64_t i = 0; i < d.n_objects; i++) {

@@ -746,22 +746,35 @@ __device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T 
     bool found = false;
     int32_t best_rank = -1;
     RT_PROF_DECL;
+    const int vote = S.leaf_vote, frac = S.leaf_frac;
     for (;;) {
-        RT_PROF(0);
-        RT_STEP_COUNT;
-        RT_MESH_LIVE;
-        const Node4Regs n = load_node4(S.nodes4, next);
-        next = node4_step(n, f, tmin32, bound32, S.ordered != 0, st, sp);
-        for (;;) {
+        if (next >= 0) {
+            RT_PROF(0);
+            RT_STEP_COUNT;
+            RT_MESH_LIVE;
+            const Node4Regs n = load_node4(S.nodes4, next);
+            next = node4_step(n, f, tmin32, bound32, S.ordered != 0, st, sp);
             if (next == RT_EMPTY) {
-                if (sp == sp0) {
-                    *t_out = max_dist;
-                    RT_PROF_FLUSH;
-                    return found;
-                }
+                if (sp == sp0) break;
                 next = st.get(--sp);
             }
-            if (next >= 0) break;
+        }
+        // The exact tests run when enough of the lanes that still walk hold a leaf (S.leaf_frac sixteenths of them, at
+        // most S.leaf_vote), or none has a node left to step through: a lane with a leaf in hand waits, the others go
+        // on with their nodes.  A test is ~130 f64 instructions and ran with 8 % of the lanes when every leaf was
+        // tested at once; a node step is ~100 of f32.  Waiting for half the lanes: knight 34.2 -> 31.6 ms (for a
+        // quarter / three quarters / all of them: 32.8 / 32.7 / 37.6).  The answer does not depend on the order of
+        // the tests (smallest t, among equal t the highest rank).
+        const uint64_t with_leaf = __ballot(next < 0);
+        if (with_leaf == 0) continue;
+        {
+            const uint64_t with_node = __ballot(next >= 0);
+            const int n_leaf = __popcll(with_leaf), n_node = __popcll(with_node);
+            const int need = frac > 0 ? min(vote, ((n_leaf + n_node) * frac + 15) >> 4) : vote;  // frac sixteenths of the lanes still walking
+            if (n_leaf < need && n_node != 0) continue;
+        }
+        bool over = false;
+        while (next < 0) {
             RT_PROF(2);
             RT_STEP_COUNT;
             const int tri = -1 - next;  // leaf: the exact test, against the current bound (t == bound passes)
@@ -776,9 +789,15 @@ __device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T 
                     found = true;
                 }
             }
-            next = RT_EMPTY;
+            if (sp == sp0) {
+                over = true;
+                break;
+            }
+            next = st.get(--sp);
         }
+        if (over) break;
     }
+    RT_PROF_FLUSH;
     *t_out = max_dist;
     return found;
 }
@@ -1928,6 +1947,9 @@ __global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend_refill(DScene
         }
         if (state == WALK) {
             // node steps until this lane holds a leaf (or is through); then the leaves of all lanes together
+            // (a vote as in blas_hit4_lane - one node step per round, the leaf round when half the lanes hold a leaf -
+            // loses here: blocks_ball 17.8 -> 18.1 ms at its best setting; the object tests of a world tree are many
+            // times a node step, and every round pays the wave's bookkeeping above)
             for (;;) {
                 if (walk.next == RT_EMPTY && !walk.pop(S, st)) {
                     state = DONE;

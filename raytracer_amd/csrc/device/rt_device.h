@@ -163,6 +163,9 @@ struct DScene {
     // The tail launch answers the queries of a wave that has at most `coop` live paths left by groups of lanes
     // (blas_hit4_group); coop_reserve: stack entries a one-lane walk of the scene's trees can need.
     int32_t coop, coop_reserve;
+    // blas_hit4_lane: the wave runs its exact triangle tests when leaf_frac sixteenths of the lanes still walking the mesh
+    // hold a leaf (at most leaf_vote lanes; leaf_frac = 0: leaf_vote lanes); the others wait with their leaf in hand
+    int32_t leaf_vote, leaf_frac;
     // Rays that start further than far_origin from the origin of coordinates (paths scattered off an unbounded Plane)
     // are moved along their line to the bounding sphere of the world BVH for the f32 box tests (kernels.hip, far_shift):
     // the padding of the boxes only covers the f32 rounding of origins near the scene.

@@ -344,6 +344,9 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_GPU_BUILD": "1"}),                     # the mesh's four-wide tree from the GPU builder (Morton order, radix tree, fold)
         ("knight", {"RT_GPU_BUILD": "1", "RT_COOP": "32"}),
         ("knight", {"RT_GPU_BUILD": "1", "RT_ORDERED": "0", "RT_FEATURES": "all"}),
+        ("knight", {"RT_LEAF_VOTE": "1"}),                     # every mesh leaf tested at once (no waiting for other lanes' leaves)
+        ("knight", {"RT_LEAF_FRAC": "16"}),                    # ... only when every lane still walking holds one
+        ("knight", {"RT_LEAF_FRAC": "0", "RT_LEAF_VOTE": "5", "RT_FEATURES": "all"}),
     ],
 )
 def test_traversal_layouts_agree_bit_for_bit(rt, gpu_scenes, name, env, monkeypatch):
