@@ -384,6 +384,7 @@ struct Tuning {
     bool all_features = false;  // RT_FEATURES=all: the general four-wide kernel whatever the scene holds
     long sweep_max = 12;        // RT_SWEEP_MAX: largest world (leaves) that is swept instead of walked
     int leaf_frac = 8;          // RT_LEAF_FRAC=d: the wave runs its exact triangle tests when d sixteenths of the lanes still in the mesh walk hold a leaf (0: RT_LEAF_VOTE alone)
+    int obj_frac = 8;           // RT_OBJ_FRAC=d: the same rule for the leaves of the world tree in closest_hit (0: an object is tested as soon as a lane holds it)
     int leaf_vote = 64;         // RT_LEAF_VOTE=n: ... or n lanes do (1: every leaf is tested at once)
     int refill = -1;            // RT_REFILL=n: k_extend_refill's threshold (-1: by scene)
     size_t grid_mult = 0;       // RT_GRID_MULT: persistent blocks per CU (0: 32, or 8 per lane while two lanes run)
@@ -416,6 +417,7 @@ struct Tuning {
         t.sweep_max = num("RT_SWEEP_MAX", 12);
         t.refill = (int)num("RT_REFILL", -1);
         t.leaf_vote = (int)std::max(1l, std::min(64l, num("RT_LEAF_VOTE", 64)));
+        t.obj_frac = (int)std::max(0l, std::min(16l, num("RT_OBJ_FRAC", 8)));
         t.leaf_frac = (int)std::max(0l, std::min(16l, num("RT_LEAF_FRAC", 8)));
         const long gm = num("RT_GRID_MULT", 0);
         t.grid_mult = gm > 0 && gm <= 65536 ? (size_t)gm : 0;
@@ -892,6 +894,8 @@ struct Engine : EngineBase {
         S.coop = tune.coop;
         S.leaf_vote = tune.leaf_vote;
         S.leaf_frac = tune.leaf_frac;
+        S.obj_frac = tune.obj_frac;
+        S.obj_frac_pad = 0;
         S.coop_reserve = stack_need4;
         S.has_meshes = S.has_media = 0;
         for (uint64_t i = 0; i < d.n_objects; i++) {

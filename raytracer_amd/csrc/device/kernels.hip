@@ -1251,12 +1251,46 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
             int32_t next = walks_node4(MODE) ? S.tlas_root4 : S.tlas_root;
             int32_t best_rank = -1;
             RT_PROF_DECL;
-            for (;;) {  // one step per iteration: one leaf (exact object test) or one node (two box tests)
+            // A node step for the lanes that hold a node, then the exact object tests for those that hold a leaf - at once
+            // (S.obj_frac = 0), or when S.obj_frac sixteenths of the lanes still walking hold one or none has a node left
+            // (a mesh leaf is a whole mesh walk: the lanes that meet the mesh had better enter it together).
+            for (;;) {
+                if (next >= 0) {
+                    if constexpr (walks_node4(MODE)) {  // four-wide step, as in blas_hit4
+                        RT_PROF(6);
+                        RT_STEP_COUNT;
+                        const Node4Regs n = load_node4(S.nodes4, next);
+                        next = node4_step<ST, (FEAT & FEAT_BLAS) != 0>(n, f, tmin32, bound32, S.ordered != 0, st, sp);
+                    } else {
+                        const Node2Regs n = load_node2(S.nodes2, next);
+                        const int32_t c0 = n.child(0), c1 = n.child(1);
+                        float e0, e1;
+                        const bool h0 = c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32, &e0);
+                        const bool h1 = c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32, &e1);
+                        next = RT_EMPTY;
+                        if (h0 && h1) {
+                            const bool far_first = S.ordered && e1 < e0;
+                            next = far_first ? c1 : c0;
+                            st.put(sp++, far_first ? c0 : c1);
+                        } else if (h0) {
+                            next = c0;
+                        } else if (h1) {
+                            next = c1;
+                        }
+                    }
+                }
                 if (next == RT_EMPTY) {
                     if (sp == 0) break;
                     next = st.get(--sp);
                 }
-                if (next < 0) {
+                if constexpr (!ST::COOP) {
+                    if (S.obj_frac > 0) {
+                        const int n_leaf = __popcll(__ballot(next < 0)), n_node = __popcll(__ballot(next >= 0));
+                        if (n_node != 0 && n_leaf < (((n_leaf + n_node) * S.obj_frac + 15) >> 4)) continue;
+                    }
+                }
+                bool over = false;
+                while (next < 0) {
                     RT_PROF(4);
                     RT_STEP_COUNT;
                     const int oi = -1 - next;
@@ -1275,29 +1309,13 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                             found = true;
                         }
                     }
-                    next = RT_EMPTY;
-                } else if constexpr (walks_node4(MODE)) {  // four-wide step, as in blas_hit4
-                    RT_PROF(6);
-                    RT_STEP_COUNT;
-                    const Node4Regs n = load_node4(S.nodes4, next);
-                    next = node4_step<ST, (FEAT & FEAT_BLAS) != 0>(n, f, tmin32, bound32, S.ordered != 0, st, sp);
-                } else {
-                    const Node2Regs n = load_node2(S.nodes2, next);
-                    const int32_t c0 = n.child(0), c1 = n.child(1);
-                    float e0, e1;
-                    const bool h0 = c0 != RT_EMPTY && box2_hit(n.lo(0), n.hi(0), f, tmin32, bound32, &e0);
-                    const bool h1 = c1 != RT_EMPTY && box2_hit(n.lo(1), n.hi(1), f, tmin32, bound32, &e1);
-                    next = RT_EMPTY;
-                    if (h0 && h1) {
-                        const bool far_first = S.ordered && e1 < e0;
-                        next = far_first ? c1 : c0;
-                        st.put(sp++, far_first ? c0 : c1);
-                    } else if (h0) {
-                        next = c0;
-                    } else if (h1) {
-                        next = c1;
+                    if (sp == 0) {
+                        over = true;
+                        break;
                     }
+                    next = st.get(--sp);
                 }
+                if (over) break;
             }
             RT_PROF_FLUSH;
             t = bound;

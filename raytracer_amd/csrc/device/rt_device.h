@@ -166,6 +166,8 @@ struct DScene {
     // blas_hit4_lane: the wave runs its exact triangle tests when leaf_frac sixteenths of the lanes still walking the mesh
     // hold a leaf (at most leaf_vote lanes; leaf_frac = 0: leaf_vote lanes); the others wait with their leaf in hand
     int32_t leaf_vote, leaf_frac;
+    // closest_hit's walk of the world tree: the same rule for its leaves, the exact object tests (0: tested at once)
+    int32_t obj_frac, obj_frac_pad;
     // Rays that start further than far_origin from the origin of coordinates (paths scattered off an unbounded Plane)
     // are moved along their line to the bounding sphere of the world BVH for the f32 box tests (kernels.hip, far_shift):
     // the padding of the boxes only covers the f32 rounding of origins near the scene.

@@ -347,6 +347,9 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_LEAF_VOTE": "1"}),                     # every mesh leaf tested at once (no waiting for other lanes' leaves)
         ("knight", {"RT_LEAF_FRAC": "16"}),                    # ... only when every lane still walking holds one
         ("knight", {"RT_LEAF_FRAC": "0", "RT_LEAF_VOTE": "5", "RT_FEATURES": "all"}),
+        ("knight", {"RT_OBJ_FRAC": "0"}),                      # the world tree's leaves tested at once / when every walking lane holds one
+        ("blocks_ball", {"RT_OBJ_FRAC": "16", "RT_REFILL": "0"}),
+        ("blocks_ball", {"RT_OBJ_FRAC": "0", "RT_REFILL": "0", "RT_COOP": "0"}),
     ],
 )
 def test_traversal_layouts_agree_bit_for_bit(rt, gpu_scenes, name, env, monkeypatch):
