@@ -383,8 +383,8 @@ struct Tuning {
     int coop = 16;              // RT_COOP=n: lane groups answer a tail wave's queries while it has at most n live paths (0: never)
     bool all_features = false;  // RT_FEATURES=all: the general four-wide kernel whatever the scene holds
     long sweep_max = 12;        // RT_SWEEP_MAX: largest world (leaves) that is swept instead of walked
-    int leaf_frac = 8;          // RT_LEAF_FRAC=d: the wave runs its exact triangle tests when d sixteenths of the lanes still in the mesh walk hold a leaf (0: RT_LEAF_VOTE alone)
-    int obj_frac = 8;           // RT_OBJ_FRAC=d: the same rule for the leaves of the world tree in closest_hit (0: an object is tested as soon as a lane holds it)
+    int leaf_frac = 5;          // RT_LEAF_FRAC=d: the wave runs its exact triangle tests when d sixteenths of the lanes still in the mesh walk hold a leaf (0: RT_LEAF_VOTE alone)
+    int obj_frac = 12;          // RT_OBJ_FRAC=d: the same rule for the leaves of the world tree in closest_hit (0: an object is tested as soon as a lane holds it)
     int leaf_vote = 64;         // RT_LEAF_VOTE=n: ... or n lanes do (1: every leaf is tested at once)
     int refill = -1;            // RT_REFILL=n: k_extend_refill's threshold (-1: by scene)
     size_t grid_mult = 0;       // RT_GRID_MULT: persistent blocks per CU (0: 32, or 8 per lane while two lanes run)
@@ -417,8 +417,8 @@ struct Tuning {
         t.sweep_max = num("RT_SWEEP_MAX", 12);
         t.refill = (int)num("RT_REFILL", -1);
         t.leaf_vote = (int)std::max(1l, std::min(64l, num("RT_LEAF_VOTE", 64)));
-        t.obj_frac = (int)std::max(0l, std::min(16l, num("RT_OBJ_FRAC", 8)));
-        t.leaf_frac = (int)std::max(0l, std::min(16l, num("RT_LEAF_FRAC", 8)));
+        t.obj_frac = (int)std::max(0l, std::min(16l, num("RT_OBJ_FRAC", 12)));
+        t.leaf_frac = (int)std::max(0l, std::min(16l, num("RT_LEAF_FRAC", 5)));
         const long gm = num("RT_GRID_MULT", 0);
         t.grid_mult = gm > 0 && gm <= 65536 ? (size_t)gm : 0;
         t.tail_blocks = (int)num("RT_TAIL_BLOCKS", 0);
@@ -1046,14 +1046,15 @@ struct Engine : EngineBase {
         }
         return h;
     }
-    // k_extend.  World trees whose leaves are whole objects (no meshes) go to k_extend_refill: node steps
-    // and object tests in separate phases, rays handed out from a launch-wide cursor (counts[1], zeroed
-    // by the k_scan_tiles before).  RT_REFILL=n: 0 = k_extend for every scene; n < 64 = lanes also take new rays
-    // while others of their wave still walk, as soon as n lanes wait (measured: slower).
+    // k_extend.  RT_REFILL=64 sends world trees to k_extend_refill instead: node steps and object tests in separate
+    // phases of the whole wave, rays handed out from a launch-wide cursor (counts[1], zeroed by the k_scan_tiles before);
+    // n < 64 = lanes also take new rays while others of their wave still walk, as soon as n lanes wait.  It was the
+    // kernel of world trees without meshes (blocks_ball 29.4 -> 23.0 ms when it came) until k_extend's own walk took
+    // one step per round with a vote on the object tests (DScene::obj_frac): blocks_ball 17.3 -> 16.8 ms, 13 spp
+    // 3.63 -> 3.25 with k_extend.
     int refill_lanes() const {
         int refill = 0;
         if (S.nodes4 && S.tlas_root4 >= 0 && S.n_sweep == 0 && !small.blob) {  // (Walk4 starts at the world tree's root)
-            refill = S.has_meshes ? 0 : 64;
             if (tune.refill >= 0) refill = tune.refill;
         }
         return refill;

@@ -773,8 +773,9 @@ __device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T 
             const int need = frac > 0 ? min(vote, ((n_leaf + n_node) * frac + 15) >> 4) : vote;  // frac sixteenths of the lanes still walking
             if (n_leaf < need && n_node != 0) continue;
         }
-        bool over = false;
-        while (next < 0) {
+        // (one test per round and lane: a lane whose next entry is a leaf again holds it for the next vote - 31.6 -> 30.3 ms
+        // against testing a lane's leaves in a row while the others wait)
+        if (next < 0) {
             RT_PROF(2);
             RT_STEP_COUNT;
             const int tri = -1 - next;  // leaf: the exact test, against the current bound (t == bound passes)
@@ -789,13 +790,9 @@ __device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T 
                     found = true;
                 }
             }
-            if (sp == sp0) {
-                over = true;
-                break;
-            }
+            if (sp == sp0) break;
             next = st.get(--sp);
         }
-        if (over) break;
     }
     RT_PROF_FLUSH;
     *t_out = max_dist;
@@ -1289,8 +1286,7 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                         if (n_node != 0 && n_leaf < (((n_leaf + n_node) * S.obj_frac + 15) >> 4)) continue;
                     }
                 }
-                bool over = false;
-                while (next < 0) {
+                if (next < 0) {  // (one test per round and lane, as in blas_hit4_lane)
                     RT_PROF(4);
                     RT_STEP_COUNT;
                     const int oi = -1 - next;
@@ -1309,13 +1305,9 @@ __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T
                             found = true;
                         }
                     }
-                    if (sp == 0) {
-                        over = true;
-                        break;
-                    }
+                    if (sp == 0) break;
                     next = st.get(--sp);
                 }
-                if (over) break;
             }
             RT_PROF_FLUSH;
             t = bound;

@@ -313,7 +313,7 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_SAH": "0", "RT_ORDERED": "0"}),
         ("knight", {"RT_REFILL": "16"}),                        # lanes take new rays while their wave still walks
         ("knight", {"RT_REFILL": "64", "RT_FEATURES": "all"}),
-        ("blocks_ball", {"RT_REFILL": "0"}),                    # k_extend instead of k_extend_refill
+        ("blocks_ball", {"RT_REFILL": "64"}),                   # k_extend_refill instead of k_extend
         ("blocks_ball", {"RT_REFILL": "5", "RT_STACK_CAP": "3"}),
         ("knight", {"RT_FEATURES": "all"}),                     # the general four-wide kernel instead of the one without media
         ("blocks_ball", {"RT_FEATURES": "all"}),                # ... instead of the one without meshes
