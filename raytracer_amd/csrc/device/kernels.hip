@@ -759,12 +759,14 @@ __device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T 
                 next = st.get(--sp);
             }
         }
-        // The exact tests run when enough of the lanes that still walk hold a leaf (S.leaf_frac sixteenths of them, at
-        // most S.leaf_vote), or none has a node left to step through: a lane with a leaf in hand waits, the others go
-        // on with their nodes.  A test is ~130 f64 instructions and ran with 8 % of the lanes when every leaf was
-        // tested at once; a node step is ~100 of f32.  Waiting for half the lanes: knight 34.2 -> 31.6 ms (for a
-        // quarter / three quarters / all of them: 32.8 / 32.7 / 37.6).  The answer does not depend on the order of
-        // the tests (smallest t, among equal t the highest rank).
+        // One step per round and lane: a node step above for the lanes that hold a node, one exact test below for those
+        // that hold a leaf - never a loop over a lane's leaves while the node lanes of the wave wait (the walk used to
+        // take the leaves off the stack and test them in a row until a node came up: knight 35.0 -> 30.0 ms without it).
+        // On top, a vote: the tests run when S.leaf_frac sixteenths of the lanes still walking hold a leaf (at most
+        // S.leaf_vote lanes), or none has a node left; a lane with a leaf in hand waits meanwhile.  A test is ~130 f64
+        // instructions, a node step ~100 of f32.  knight at 0 (no waiting) / 3 / 5 / 8 / 12 / 16 sixteenths: 30.0 /
+        // 30.0 / 29.7 / 30.3 / 32.3 / 42.8 ms.  The answer does not depend on the order of the tests (smallest t,
+        // among equal t the highest rank).
         const uint64_t with_leaf = __ballot(next < 0);
         if (with_leaf == 0) continue;
         {
@@ -773,8 +775,6 @@ __device__ bool blas_hit4_lane(const DScene<T>& S, const Ray<T>& r, int root, T 
             const int need = frac > 0 ? min(vote, ((n_leaf + n_node) * frac + 15) >> 4) : vote;  // frac sixteenths of the lanes still walking
             if (n_leaf < need && n_node != 0) continue;
         }
-        // (one test per round and lane: a lane whose next entry is a leaf again holds it for the next vote - 31.6 -> 30.3 ms
-        // against testing a lane's leaves in a row while the others wait)
         if (next < 0) {
             RT_PROF(2);
             RT_STEP_COUNT;
