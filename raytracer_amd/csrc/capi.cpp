@@ -481,6 +481,7 @@ struct Engine : EngineBase {
     DevBuf<rtd::DImage> images;
     DevBuf<uint8_t> texels;
     DevBuf<int32_t> top_list, sweep;
+    DevBuf<int4> sweep_items;
     DevBuf<unsigned char> small_blob;
     rtd::DSmallScene small;
     // work buffers: one lane = one stream + one set of queues (render_accum deals its batches over the lanes)
@@ -921,6 +922,8 @@ struct Engine : EngineBase {
             S.sweep = nullptr;
             S.n_sweep = 0;
             S.lean = 0;
+            S.sweep_items = nullptr;
+            S.n_sweep_items = 0;
             std::memset(&small, 0, sizeof(small));
         }
         if (tune.debug)
@@ -951,6 +954,9 @@ struct Engine : EngineBase {
         S.sweep = nullptr;
         S.n_sweep = 0;
         S.lean = 0;
+        S.sweep_items = nullptr;
+        S.n_sweep_items = 0;
+        S.sweep_items_pad = 0;
         if (d.tlas_root < 0) return;
         const long limit = tune.sweep_max;
         std::vector<int32_t> order, todo{d.tlas_root};
@@ -982,6 +988,24 @@ struct Engine : EngineBase {
         sweep.upload(order);
         S.sweep = sweep.p;
         S.n_sweep = (int32_t)order.size();
+        // A world that is nothing but swept rect lists (cornell): its rects one by one, for the lane groups at the end
+        // of a tail launch (kernels.hip, sweep_hit_group).
+        if (S.lean && d.n_top == 1 && d.top_list[0] == RT_TOP_BVH) {
+            std::vector<int4> items;
+            for (size_t k = 0; k < order.size(); k++) {
+                const rt_object& ob = d.objects[order[k]];
+                if (ob.kind != RT_OBJ_RECTS) {
+                    items.clear();
+                    break;
+                }
+                for (int32_t j = 0; j < ob.count; j++) items.push_back(int4{order[k], ob.first + j, ob.xform, (int32_t)k});
+            }
+            if (!items.empty() && items.size() <= 256) {
+                sweep_items.upload(items);
+                S.sweep_items = sweep_items.p;
+                S.n_sweep_items = (int32_t)items.size();
+            }
+        }
     }
 
     // Packs the traversal records of a small scene into one blob for LDS staging (k_extend<.., true>).

@@ -1157,6 +1157,46 @@ __device__ bool world_hit4_group(const DScene<T>& S, const Ray<T>& ray, T min_di
     return true;
 }
 
+// world.hit for a swept world of rect lists, answered by a group of G lanes that all hold the same ray (the end of a tail
+// launch, where a wave is down to a few paths and a lone lane would test the rects one after the other): lane gl of the
+// group takes the rects gl, gl + G, .. of S.sweep_items, each in its object's space, each exactly as rects_hit_uniform
+// tests it; the group's answer is the sweep's: the smallest t, among equal t the object that comes LATER in the sweep
+// (an object is tested against the bound the earlier ones left, and t == bound passes), within one object the EARLIER rect
+// (strict < keeps the first, src/hitting.rs:88-104).  Every lane of the group returns the same answer.
+template <typename T>
+__device__ __forceinline__ bool sweep_hit_group(const DScene<T>& S, const Ray<T>& ray, T min_dist, int G, T* t_out, Winner* w_out) {
+    const int gl = (int)(threadIdx.x & 63u) & (G - 1);
+    bool have = false;
+    T bt = 0;
+    int b_k = -1, b_rect = -1, b_obj = -1;
+    for (int i = gl; i < S.n_sweep_items; i += G) {
+        const int4 it = S.sweep_items[i];  // (object, rect, transform, place in the sweep)
+        Ray<T> r = ray;
+        if (it.z >= 0) r = to_object_space(S.xforms[it.z], ray);
+        T th;
+        if (rect_hit(S.rects[it.y], r, min_dist, Lim<T>::inf(), &th)) {
+            // (a lane's rects come in the sweep's order: a later object takes an equal t, a later rect of the same object does not)
+            if (!have || th < bt || (th == bt && it.w != b_k)) {
+                bt = th; b_k = it.w; b_rect = it.y; b_obj = it.x;
+            }
+            have = true;
+        }
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) {
+        const bool o_have = __shfl_xor((int)have, off) != 0;
+        const T o_t = __shfl_xor(bt, off);
+        const int o_k = __shfl_xor(b_k, off), o_rect = __shfl_xor(b_rect, off), o_obj = __shfl_xor(b_obj, off);
+        const bool take = o_have && (!have || o_t < bt || (o_t == bt && (o_k > b_k || (o_k == b_k && o_rect < b_rect))));
+        if (take) {
+            bt = o_t; b_k = o_k; b_rect = o_rect; b_obj = o_obj;
+        }
+        have = have || o_have;
+    }
+    *t_out = bt;
+    *w_out = Winner{b_obj, b_rect};
+    return have;
+}
+
 template <typename T, int MODE, typename ST>
 __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T max_dist, ST st, PathRef path,
                             uint32_t depth, T* t_out, Winner* w_out) {
@@ -2386,6 +2426,34 @@ __global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND
             // one lane's pace): each live path's query is answered by a group of 64 / 32 / 16 / 8 lanes.
             Answer ans;
             bool grouped = false;
+            if constexpr (MODE == WALK_SWEEP_LEAN) {
+                // a swept world of rect lists: a wave down to a few paths shares each path's rects out among a group of lanes
+                const uint64_t live = __ballot(alive);
+                const int n_live = __popcll(live);
+                if (__builtin_expect(S.sweep_items != nullptr && n_live <= S.coop, 0)) {  // (wave-uniform)
+                    const int G = n_live <= 1 ? 64 : n_live <= 2 ? 32 : n_live <= 4 ? 16 : n_live <= 8 ? 8 : n_live <= 16 ? 4 : 2;
+                    const int group = (int)lane / G;
+                    uint64_t rest = live;
+                    for (int k = 0; k < group && rest; k++) rest &= rest - 1;
+                    const bool has_ray = rest != 0;
+                    const int owner = has_ray ? __ffsll((long long)rest) - 1 : 0;  // the group-th live lane
+                    Ray<T> gr;
+                    gr.o = mk(__shfl(ray.o.x, owner), __shfl(ray.o.y, owner), __shfl(ray.o.z, owner));
+                    gr.d = mk(__shfl(ray.d.x, owner), __shfl(ray.d.y, owner), __shfl(ray.d.z, owner));
+                    gr.time = __shfl(ray.time, owner);
+                    T g_t = 0;
+                    Winner g_w{-1, -1};
+                    bool g_hit = false;
+                    // (every lane runs the group's reduction; a group without a path tests nothing)
+                    g_hit = sweep_hit_group<T>(W, gr, has_ray ? (T)0.001 : Lim<T>::inf(), G, &g_t, &g_w);
+                    const int from = __popcll(live & ((1ull << lane) - 1ull)) * G;  // the k-th live lane reads lane 0 of group k
+                    ans.hit = __shfl((int)g_hit, from & 63) != 0;
+                    ans.t = __shfl(g_t, from & 63);
+                    ans.w.obj = __shfl(g_w.obj, from & 63);
+                    ans.w.prim = __shfl(g_w.prim, from & 63);
+                    grouped = true;
+                }
+            }
             if constexpr (COOP_MODE) {
                 const uint64_t live = __ballot(alive);
                 const int n_live = __popcll(live);

@@ -152,6 +152,10 @@ struct DScene {
     const uint8_t* texels;
     const int32_t* top_list;
     const int32_t* sweep;  // leaves (object indices) of a small world BVH in depth-first order; n_sweep == 0: walk the tree
+    // the rects of a swept world of rect lists only, one by one in the sweep's order: {object, rect, transform, place of the
+    // object in the sweep} - what a group of lanes shares out when it answers one ray's query (sweep_hit_group); nullptr: no groups
+    const int4* sweep_items;
+    int32_t n_sweep_items, sweep_items_pad;
     int32_t n_top, tlas_root /* DNode2 super-root */, tlas_root_own /* DNode index */, n_sweep;
     int32_t lean;     // every object is a rect list or a sphere (no meshes, media, planes, lone triangles)
     int32_t ordered;  // tree walks enter the nearer child first (results are the same either way)
