@@ -980,17 +980,20 @@ struct Engine : EngineBase {
             todo.push_back(nd.left);
         }
         if (order.empty()) return;
+        // which sweep kernel: 1 = rect lists and spheres only (cornell, globe), 2 = no meshes and no media anywhere
+        // (two_spheres: planes too), 0 = the general one (blue_ball's medium)
         S.lean = 1;
         for (uint64_t i = 0; i < d.n_objects; i++) {
             const int32_t k = d.objects[i].kind;
-            if (k != RT_OBJ_RECTS && k != RT_OBJ_SPHERE && k != RT_OBJ_MOVING_SPHERE) S.lean = 0;
+            if (k == RT_OBJ_BLAS || k == RT_OBJ_MEDIUM) S.lean = 0;
+            else if (k != RT_OBJ_RECTS && k != RT_OBJ_SPHERE && k != RT_OBJ_MOVING_SPHERE && S.lean == 1) S.lean = 2;
         }
         sweep.upload(order);
         S.sweep = sweep.p;
         S.n_sweep = (int32_t)order.size();
         // A world that is nothing but swept rect lists (cornell): its rects one by one, for the lane groups at the end
         // of a tail launch (kernels.hip, sweep_hit_group).
-        if (S.lean && d.n_top == 1 && d.top_list[0] == RT_TOP_BVH) {
+        if (S.lean == 1 && d.n_top == 1 && d.top_list[0] == RT_TOP_BVH) {
             std::vector<int4> items;
             for (size_t k = 0; k < order.size(); k++) {
                 const rt_object& ob = d.objects[order[k]];
@@ -1109,7 +1112,7 @@ struct Engine : EngineBase {
         size_t blocks = (n + 255) / 256;
         const int env_blocks = tune.tail_blocks;  // (A/B runs of builds with other tail_waves())
         // blocks that stay resident per CU = the waves per SIMD the scene's tail kernel is compiled for (kernels.hip, tail_waves)
-        const int resident = S.n_sweep > 0 && S.lean ? 3 : S.nodes4 && S.has_meshes ? 4 : tail_blocks_per_cu;
+        const int resident = S.n_sweep > 0 && S.lean != 0 ? 3 : S.nodes4 && S.has_meshes ? 4 : tail_blocks_per_cu;
         const size_t cap = (size_t)num_cus * (env_blocks > 0 ? env_blocks : resident);
         return (int)(blocks < 1 ? 1 : blocks > cap ? cap : blocks);
     }
@@ -1226,11 +1229,13 @@ struct Engine : EngineBase {
         const uint32_t spb = (ns + n_batches - 1) / n_batches;
         n_batches = (ns + spb - 1) / spb;
         const bool timing = stats != nullptr && time_launches && !fixed;
-        // One fused launch per bounce pays off when the traversal is the lean sweep (no stack, no spills:
-        // cornell 30.5 -> 25.2 ms); with a divergent tree walk the shading half runs at the walk's low
-        // occupancy and loses (knight 95 -> 107 ms).  RT_FUSE=0 / 1 (environment) overrides for A/B runs.
+        // One fused launch per bounce pays off when the traversal is a sweep (no divergent walk: cornell 30.5 -> 25.2 ms
+        // when it came; the sweeps that are not lean followed at the end of round 3, once the shading had lost its
+        // per-lane rejection loop and its scratch memory: two_spheres 12.45 -> 10.0 ms, blue_ball 25.7 -> 22.0); with
+        // a divergent tree walk the shading half runs at the walk's low occupancy and loses (knight 95 -> 107 ms).
+        // RT_FUSE=0 / 1 (environment) overrides for A/B runs.
         const bool debug_counts = tune.debug;
-        const bool fused = tune.fuse >= 0 ? tune.fuse != 0 : (S.n_sweep > 0 && S.lean);
+        const bool fused = tune.fuse >= 0 ? tune.fuse != 0 : S.n_sweep > 0;
         // Paths alive at or below which the tail launch takes over (RT_TAIL=n in the environment overrides, 0: never).
         // The tail launch hands its paths out from a cursor, so it stays efficient with many more paths than are
         // resident at a time; what it saves is the wait for the slowest ray of every bounce.

@@ -1059,10 +1059,12 @@ __device__ RT_MEDIUM_ATTR bool medium_hit(const DScene<T>& S, const DObject ob, 
 enum { WALK_NODE2 = 0, WALK_OWN_BOX_LDS = 1, WALK_SWEEP = 2, WALK_SWEEP_LEAN = 3 /* rect lists and spheres only */,
        WALK_NODE2_MESH4 = 4 /* four-wide world and mesh trees, every object kind */,
        // the same walk compiled without the object kinds a scene does not hold (smaller kernels, fewer spills):
-       WALK_NODE4_MESH = 5 /* no media */, WALK_NODE4_MEDIA = 6 /* no meshes */, WALK_NODE4_PLAIN = 7 /* neither */ };
-constexpr bool walks_node4(int mode) { return mode >= WALK_NODE2_MESH4; }
+       WALK_NODE4_MESH = 5 /* no media */, WALK_NODE4_MEDIA = 6 /* no meshes */, WALK_NODE4_PLAIN = 7 /* neither */,
+       WALK_SWEEP_FLAT = 8 /* a sweep of a scene without meshes or media: rect lists, spheres, planes, triangles */ };
+constexpr bool walks_node4(int mode) { return mode >= WALK_NODE2_MESH4 && mode <= WALK_NODE4_PLAIN; }
 template <int MODE> struct WalkFeat {
     static constexpr int value = MODE == WALK_SWEEP_LEAN     ? FEAT_SPHERES
+                                 : MODE == WALK_SWEEP_FLAT   ? (FEAT_SPHERES | FEAT_FLAT)
                                  : MODE == WALK_NODE2_MESH4  ? (FEAT_ALL | FEAT_BLAS4 | FEAT_NESTED_MEDIA)
                                  : MODE == WALK_NODE4_MESH   ? ((FEAT_ALL & ~FEAT_MEDIA) | FEAT_BLAS4)
                                  : MODE == WALK_NODE4_MEDIA  ? (FEAT_ALL & ~FEAT_BLAS)
@@ -1200,7 +1202,7 @@ __device__ __forceinline__ bool sweep_hit_group(const DScene<T>& S, const Ray<T>
 template <typename T, int MODE, typename ST>
 __device__ bool closest_hit(const DScene<T>& S, const Ray<T>& ray, T min_dist, T max_dist, ST st, PathRef path,
                             uint32_t depth, T* t_out, Winner* w_out) {
-    constexpr bool SWEEP = MODE == WALK_SWEEP || MODE == WALK_SWEEP_LEAN;
+    constexpr bool SWEEP = MODE == WALK_SWEEP || MODE == WALK_SWEEP_LEAN || MODE == WALK_SWEEP_FLAT;
     constexpr bool UNI = SWEEP;  // the top-level list is walked in step by all lanes
     constexpr int FEAT = WalkFeat<MODE>::value;
     bool have = false;
@@ -1512,7 +1514,7 @@ constexpr int tail_waves(int mode) {
 #ifdef RT_TAIL_WAVES
     return RT_TAIL_WAVES;
 #else
-    return mode == 3 /* WALK_SWEEP_LEAN */ ? 3 : (mode == 4 || mode == 5) /* WALK_NODE2_MESH4, WALK_NODE4_MESH */ ? 4 : 2;
+    return mode == 3 /* WALK_SWEEP_LEAN */ || mode == 8 /* WALK_SWEEP_FLAT */ ? 3 : (mode == 4 || mode == 5) /* WALK_NODE2_MESH4, WALK_NODE4_MESH */ ? 4 : 2;
 #endif
 }
 template <int MODE, bool DEEP = walks_node4(MODE)> struct StackFor {
@@ -2755,8 +2757,10 @@ template <typename T>
 void Launch<T>::extend(const DScene<T>& S, const DSmallScene& small, const DBatch& B, DQueue<T> q, DHits<T> h, const T* tmin, const T* tmax,
                        uint32_t depth, const uint32_t* tile_offsets, uint32_t n_tiles, int stack, int grid_blocks,
                        uint32_t* cursor, int refill, hipStream_t st) {
-    if (S.n_sweep > 0 && S.lean)
+    if (S.n_sweep > 0 && S.lean == 1)
         hipLaunchKernelGGL((k_extend<T, 1, WALK_SWEEP_LEAN>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
+    else if (S.n_sweep > 0 && S.lean == 2)
+        hipLaunchKernelGGL((k_extend<T, 1, WALK_SWEEP_FLAT>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (S.n_sweep > 0 && stack <= 16)
         hipLaunchKernelGGL((k_extend<T, 16, WALK_SWEEP>), dim3(grid_blocks), dim3(BLOCK), 0, st, S, small, B, q, h, tmin, tmax, depth, tile_offsets, n_tiles);
     else if (S.n_sweep > 0)
@@ -2816,7 +2820,8 @@ void Launch<T>::bounce(const DScene<T>& S, const DSmallScene& small, const DBatc
         else if (n_first) RT_BOUNCE_(STACK, MODE, false, true); \
         else RT_BOUNCE_(STACK, MODE, false, false);             \
     } while (0)
-    if (S.n_sweep > 0 && S.lean) RT_BOUNCE_SWEEP(1, WALK_SWEEP_LEAN);
+    if (S.n_sweep > 0 && S.lean == 1) RT_BOUNCE_SWEEP(1, WALK_SWEEP_LEAN);
+    else if (S.n_sweep > 0 && S.lean == 2) RT_BOUNCE_SWEEP(1, WALK_SWEEP_FLAT);
     else if (S.n_sweep > 0 && stack <= 16) RT_BOUNCE_SWEEP(16, WALK_SWEEP);
     else if (S.n_sweep > 0) RT_BOUNCE_SWEEP(64, WALK_SWEEP);
     else if (small.blob && stack <= 16) RT_BOUNCE(16, WALK_OWN_BOX_LDS);

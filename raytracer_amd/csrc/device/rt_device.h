@@ -157,7 +157,7 @@ struct DScene {
     const int4* sweep_items;
     int32_t n_sweep_items, sweep_items_pad;
     int32_t n_top, tlas_root /* DNode2 super-root */, tlas_root_own /* DNode index */, n_sweep;
-    int32_t lean;     // every object is a rect list or a sphere (no meshes, media, planes, lone triangles)
+    int32_t lean;     // 1: every object is a rect list or a sphere (no meshes, media, planes, lone triangles); 2: no meshes and no media (WALK_SWEEP_FLAT)
     int32_t ordered;  // tree walks enter the nearer child first (results are the same either way)
     int32_t needs_uv;  // some material reads (u, v): image textures, checkers
     int32_t tlas_root4;  // world BVH in nodes4 (valid when nodes4 != nullptr)

@@ -347,6 +347,10 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_LEAF_VOTE": "1"}),                     # every mesh leaf tested at once (no waiting for other lanes' leaves)
         ("knight", {"RT_LEAF_FRAC": "16"}),                    # ... only when every lane still walking holds one
         ("knight", {"RT_LEAF_FRAC": "0", "RT_LEAF_VOTE": "5", "RT_FEATURES": "all"}),
+        ("two_spheres", {"RT_FUSE": "0"}),                     # k_extend + k_shade instead of the fused bounce of a sweep without meshes or media (WALK_SWEEP_FLAT)
+        ("two_spheres", {"RT_TAIL": "0", "RT_FUSE_RAYGEN": "0"}),
+        ("two_spheres", {"RT_TAIL": "100000000"}),             # every bounce in the tail launch
+        ("blue_ball", {"RT_FUSE": "0"}),                       # the general sweep, two kernels per bounce
         ("cornell", {"RT_COOP": "0"}),                         # no lane groups at the end of the tail launch (a swept world of rect lists shares a path's rects out)
         ("cornell", {"RT_COOP": "32", "RT_TAIL": "100000000"}),  # ... groups from 32 live paths down, every bounce in the tail launch
         ("knight", {"RT_OBJ_FRAC": "0"}),                      # the world tree's leaves tested at once / when every walking lane holds one
