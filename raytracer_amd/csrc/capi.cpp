@@ -1235,7 +1235,11 @@ struct Engine : EngineBase {
         // a divergent tree walk the shading half runs at the walk's low occupancy and loses (knight 95 -> 107 ms).
         // RT_FUSE=0 / 1 (environment) overrides for A/B runs.
         const bool debug_counts = tune.debug;
-        const bool fused = tune.fuse >= 0 ? tune.fuse != 0 : S.n_sweep > 0;
+        // World trees without meshes (blocks_ball) are fused too since the end of round 3: 16.8 -> 15.9 ms, 13 spp 3.22 -> 3.09
+        // through a k_bounce compiled without the bounce loop; with meshes it is a tie (knight 30.2 / 29.7, 1 M triangles
+        // 38.7 / 39.0) and the two kernels stay.
+        const bool tree_without_meshes = S.n_sweep == 0 && !(small.blob && stack_depth <= 16) && S.nodes4 && !S.has_meshes;
+        const bool fused = tune.fuse >= 0 ? tune.fuse != 0 : (S.n_sweep > 0 || tree_without_meshes);
         // Paths alive at or below which the tail launch takes over (RT_TAIL=n in the environment overrides, 0: never).
         // The tail launch hands its paths out from a cursor, so it stays efficient with many more paths than are
         // resident at a time; what it saves is the wait for the slowest ray of every bounce.

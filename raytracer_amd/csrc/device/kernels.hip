@@ -2831,11 +2831,26 @@ void Launch<T>::bounce(const DScene<T>& S, const DSmallScene& small, const DBatc
         else if (stack <= 32) RT_BOUNCE(32, MODE); \
         else RT_BOUNCE(64, MODE);              \
     } while (0)
+    // world trees without meshes run their bounces fused (capi.cpp): the launches that are not the tail launch take the
+    // kernel compiled without the bounce loop (48 registers fewer spilled on blocks_ball)
+#define RT_BOUNCE_T(STACK, MODE)                                \
+    do {                                                        \
+        if (tail) RT_BOUNCE_(STACK, MODE, true, false);         \
+        else RT_BOUNCE_(STACK, MODE, false, false);             \
+    } while (0)
+#define RT_BOUNCE4_T(MODE)                       \
+    do {                                         \
+        if (stack <= 16) RT_BOUNCE_T(16, MODE);  \
+        else if (stack <= 32) RT_BOUNCE_T(32, MODE); \
+        else RT_BOUNCE_T(64, MODE);              \
+    } while (0)
     else if (S.nodes4 && S.has_meshes && S.has_media) RT_BOUNCE4(WALK_NODE2_MESH4);
     else if (S.nodes4 && S.has_meshes) RT_BOUNCE4(WALK_NODE4_MESH);
-    else if (S.nodes4 && S.has_media) RT_BOUNCE4(WALK_NODE4_MEDIA);
-    else if (S.nodes4) RT_BOUNCE4(WALK_NODE4_PLAIN);
+    else if (S.nodes4 && S.has_media) RT_BOUNCE4_T(WALK_NODE4_MEDIA);
+    else if (S.nodes4) RT_BOUNCE4_T(WALK_NODE4_PLAIN);
 #undef RT_BOUNCE4
+#undef RT_BOUNCE4_T
+#undef RT_BOUNCE_T
     else if (stack <= 16) RT_BOUNCE(16, WALK_NODE2);
     else if (stack <= 32) RT_BOUNCE(32, WALK_NODE2);
     else RT_BOUNCE(64, WALK_NODE2);

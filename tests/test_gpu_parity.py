@@ -313,8 +313,8 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("knight", {"RT_SAH": "0", "RT_ORDERED": "0"}),
         ("knight", {"RT_REFILL": "16"}),                        # lanes take new rays while their wave still walks
         ("knight", {"RT_REFILL": "64", "RT_FEATURES": "all"}),
-        ("blocks_ball", {"RT_REFILL": "64"}),                   # k_extend_refill instead of k_extend
-        ("blocks_ball", {"RT_REFILL": "5", "RT_STACK_CAP": "3"}),
+        ("blocks_ball", {"RT_REFILL": "64", "RT_FUSE": "0"}),   # two kernels per bounce, k_extend_refill instead of k_extend
+        ("blocks_ball", {"RT_REFILL": "5", "RT_STACK_CAP": "3", "RT_FUSE": "0"}),
         ("knight", {"RT_FEATURES": "all"}),                     # the general four-wide kernel instead of the one without media
         ("blocks_ball", {"RT_FEATURES": "all"}),                # ... instead of the one without meshes
         ("knight", {"RT_STACK_CAP": "6"}),                   # four-wide walk mostly on the private overflow stack
@@ -354,7 +354,7 @@ def test_bad_arguments_are_errors_not_faults(rt, gpu_scenes):
         ("cornell", {"RT_COOP": "0"}),                         # no lane groups at the end of the tail launch (a swept world of rect lists shares a path's rects out)
         ("cornell", {"RT_COOP": "32", "RT_TAIL": "100000000"}),  # ... groups from 32 live paths down, every bounce in the tail launch
         ("knight", {"RT_OBJ_FRAC": "0"}),                      # the world tree's leaves tested at once / when every walking lane holds one
-        ("blocks_ball", {"RT_OBJ_FRAC": "16", "RT_REFILL": "0"}),
+        ("blocks_ball", {"RT_OBJ_FRAC": "16", "RT_FUSE": "0"}),   # k_extend + k_shade (world trees without meshes are fused by default)
         ("blocks_ball", {"RT_OBJ_FRAC": "0", "RT_REFILL": "0", "RT_COOP": "0"}),
     ],
 )
