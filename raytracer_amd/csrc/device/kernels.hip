@@ -1517,6 +1517,10 @@ constexpr int tail_waves(int mode) {
     return mode == 3 /* WALK_SWEEP_LEAN */ || mode == 8 /* WALK_SWEEP_FLAT */ ? 3 : (mode == 4 || mode == 5) /* WALK_NODE2_MESH4, WALK_NODE4_MESH */ ? 4 : 2;
 #endif
 }
+// Waves per SIMD the per-bounce k_bounce is compiled for: the fused bounce of a world tree with media (walk, medium test
+// and shading in one kernel) needs 168 registers - at 4 waves it spills 48 of them, at 3 five: blocks_ball 16.0 -> 15.5 ms.
+// (f64 only: in f32 the kernel fits and the fourth wave is worth 10 %)
+constexpr int bounce_waves(int mode, size_t elem) { return mode == 6 /* WALK_NODE4_MEDIA */ && elem == 8 ? 3 : RT_EXTEND_WAVES; }
 template <int MODE, bool DEEP = walks_node4(MODE)> struct StackFor {
     typedef Stack type;
     static constexpr int SPILL = 1;
@@ -2302,7 +2306,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DScene<T> S, DB
 // read from a queue k_raygen has written - 84 B per path that are neither written nor read, and one launch fewer
 // (cornell: k_raygen was 0.65 ms of a 19.5 ms image, globe: of 3.0 ms).  Slot d of the dense batch is path d's place.
 template <typename T, int STACK, int MODE, bool CAN_TAIL, bool FIRST = false>
-__global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : RT_EXTEND_WAVES) k_bounce(DScene<T> S, DSmallScene small, DBatch B, DQueue<T> qin, DQueue<T> qout,
+__global__ void __launch_bounds__(BLOCK, CAN_TAIL ? tail_waves(MODE) : bounce_waves(MODE, sizeof(T))) k_bounce(DScene<T> S, DSmallScene small, DBatch B, DQueue<T> qin, DQueue<T> qout,
                                                                     T* sample_rgb, uint32_t depth0, uint32_t max_bounces,
                                                                     const uint32_t* __restrict__ tile_offsets,
                                                                     uint32_t* tile_counts_out, uint32_t n_tiles, DTail tail, uint32_t n_first) {
