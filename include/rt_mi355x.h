@@ -204,7 +204,8 @@ typedef struct rt_upload_stats {
     uint32_t n_nodes2, n_nodes4, sah_trees;
     uint32_t needs_uv;     /* some material reads (u, v) (image textures, checkers): hit records carry them (16 B more each way) */
     uint32_t gpu_built_trees; /* mesh trees built by the GPU builder (csrc/device/bvh_build.hip) instead of the host's SAH regrouping */
-    uint32_t pad;
+    uint32_t walk;         /* how rays meet the world: low byte 0 = a tree walk, 1 / 2 / 3 = a sweep of its <= 12 objects through the kernel for rect lists and
+                              spheres / for scenes without meshes and media / for every object kind; bits 8..: rects listed one by one for the lane groups */
     double ms_gpu_build;   /* leaf collection on the host + copies + the GPU build of those trees (part of ms_build) */
 } rt_upload_stats;
 int rt_get_upload_stats(rt_context* ctx, rt_upload_stats* out);

@@ -66,7 +66,7 @@ class RtUploadStats(C.Structure):
     _fields_ = [
         ("ms_validate", C.c_double), ("ms_build", C.c_double), ("ms_copy", C.c_double), ("ms_total", C.c_double),
         ("bytes_device", C.c_uint64), ("n_nodes2", C.c_uint32), ("n_nodes4", C.c_uint32), ("sah_trees", C.c_uint32),
-        ("needs_uv", C.c_uint32), ("gpu_built_trees", C.c_uint32), ("pad", C.c_uint32), ("ms_gpu_build", C.c_double),
+        ("needs_uv", C.c_uint32), ("gpu_built_trees", C.c_uint32), ("walk", C.c_uint32), ("ms_gpu_build", C.c_double),
     ]
 
     def as_dict(self) -> dict:

@@ -937,6 +937,7 @@ struct Engine : EngineBase {
         up_stats.n_nodes4 = (uint32_t)(S.nodes4 ? nodes4.n : 0);
         up_stats.sah_trees = sah_trees ? 1u : 0u;
         up_stats.needs_uv = S.needs_uv ? 1u : 0u;
+        up_stats.walk = (S.n_sweep > 0 ? (S.lean == 1 ? 1u : S.lean == 2 ? 2u : 3u) : 0u) | ((uint32_t)S.n_sweep_items << 8);
         up_stats.bytes_device = nodes2.n * sizeof(rtd::DNode2) + (S.nodes4 ? nodes4.n * sizeof(rtd::DNode4) : 0) + objects.n * sizeof(rtd::DObject) +
                                 blocks.n * sizeof(rtd::DBlock<T>) + xforms.n * sizeof(rtd::DXform<T>) + spheres.n * sizeof(rtd::DSphere<T>) +
                                 moving_spheres.n * sizeof(rtd::DMovingSphere<T>) + rects.n * sizeof(rtd::DRect<T>) +

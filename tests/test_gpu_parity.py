@@ -730,3 +730,14 @@ def test_fast_mode_hit_ids_against_the_oracle(gpu_scenes, rt, name):
     ok = both & same
     t_err = np.abs(got["t"][ok] - want["t"][ok]) / np.maximum(np.abs(want["t"][ok]), 1e-300)
     assert np.quantile(t_err, 0.99) <= 1e-4 and t_err.max() <= 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name, kind, rects", [("cornell", 1, 18), ("globe", 1, 0), ("two_spheres", 2, 0), ("blue_ball", 3, 0), ("blocks_ball", 0, 0), ("knight", 0, 0)])
+def test_which_walk_a_scene_gets(rt, gpu_scenes, name, kind, rects):
+    # the kernel family chosen at upload (rt_upload_stats.walk): the cheap sweep kernels are what the measured numbers rest on -
+    # a scene that silently fell back to the general one would still render the same image
+    _, r = gpu_scenes(name)
+    walk = r.upload_stats().walk
+    assert walk & 0xFF == kind
+    assert walk >> 8 == rects  # cornell's 18 rects are listed one by one for the lane groups of the tail launch
